@@ -1,0 +1,416 @@
+"""CPU oracle for the VITA vision-latent -> action-latent flow-matching hot path.
+
+THIS FILE IS TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke()
+and bench.py's cpu_baseline leg may import it.  The product path (vita_amd/) never
+imports it and fails loudly when the HIP library is missing.
+
+It is a functional (no nn.Module) restatement, on torch CPU tensors, of the reference
+algorithm, op for op, each function citing the reference file:line it follows.  Weights
+come in as a flat ``dict[str, Tensor]`` keyed by the reference's state-dict names
+(SURVEY.md section 8(b)), so a reference checkpoint drops in unchanged.
+
+Pinning (tools/gen_golden.py, run in the build container where /root/reference exists):
+  * PINNED against the reference's own modules loaded from /root/reference by file path:
+    SinusoidalPosEmbed, SimpleFlowNet (+FlowNetLayer), TorchFlowMatcher.sample,
+    CNNActionEncoder, SimpleActionEncoder, SimpleActionDecoder, Normalize/Unnormalize,
+    compute_contrastive_loss, DiagonalGaussianDistribution.kl.  Outputs are committed
+    under tests/golden/ and test_oracle_golden.py checks this file against them.
+  * RESTATED, UNPINNED (third-party code absent from this image and from /root/reference):
+    timm==1.0.20 ``timm.layers.Mlp`` op order (fc1 -> act -> drop -> norm(Identity) ->
+    fc2 -> drop); torchcfm==1.0.5 ``ConditionalFlowMatcher.sample_location_and_conditional_flow``
+    (xt = t*x1 + (1-t)*x0 + sigma*eps, ut = x1 - x0) and the exact-OT re-pairing (POT);
+    diffusers==0.30.3 EMAModel decay and cosine-with-warmup schedule.  These follow the
+    published sources of the pinned versions; none of the reference's files hold outputs
+    for them.
+
+All functions are dtype-generic: pass float64 weights/inputs to get the fp64 "truth"
+used to bound the fp32 error of both the reference and the HIP path.
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+SD = dict  # state dict: reference key -> tensor
+
+
+# ----------------------------------------------------------------------------------------
+# primitives
+# ----------------------------------------------------------------------------------------
+def sinusoidal_pos_embed(t: Tensor, dim: int = 256) -> Tensor:
+    """flare/models/pos_embed.py:11-18.  t (B,) -> (B, dim) = cat(sin(t f), cos(t f))."""
+    half = dim // 2
+    emb = math.log(10000) / (half - 1)
+    # reference builds the frequency table in the default dtype (fp32) from arange
+    freqs = torch.exp(torch.arange(half, device=t.device) * -emb)
+    if t.dtype == torch.float64:
+        freqs = torch.exp(torch.arange(half, device=t.device, dtype=torch.float64) * -emb)
+    e = t[:, None] * freqs[None, :]
+    return torch.cat((e.sin(), e.cos()), dim=-1)
+
+
+def timm_mlp(x: Tensor, sd: SD, prefix: str, act: Callable[[Tensor], Tensor]) -> Tensor:
+    """timm==1.0.20 timm.layers.Mlp.forward (RESTATED, UNPINNED): fc2(act(fc1(x))) with
+    drop=0 and norm=Identity.  Call sites: simple_flow_net.py:19-24, action_ae.py:139-146,
+    245-252."""
+    h = F.linear(x, sd[prefix + "fc1.weight"], sd[prefix + "fc1.bias"])
+    h = act(h)
+    return F.linear(h, sd[prefix + "fc2.weight"], sd[prefix + "fc2.bias"])
+
+
+def gelu_tanh(x: Tensor) -> Tensor:
+    return F.gelu(x, approximate="tanh")
+
+
+def gelu_exact(x: Tensor) -> Tensor:
+    return F.gelu(x)
+
+
+# ----------------------------------------------------------------------------------------
+# SimpleFlowNet  (flare/policies/vita/simple_flow_net.py)
+# ----------------------------------------------------------------------------------------
+def flow_net_num_layers(sd: SD, prefix: str = "flow_net.") -> int:
+    n = 0
+    while f"{prefix}layers.{n}.mlp.fc1.weight" in sd:
+        n += 1
+    return n
+
+
+def flow_net_time_embed(sd: SD, t: Tensor, prefix: str = "flow_net.") -> Tensor:
+    """simple_flow_net.py:66-71,101: Linear(1024->H) o Mish o Linear(256->1024) o Sinusoid(256)."""
+    time_embed_dim = sd[prefix + "time_embed.1.weight"].shape[1]
+    e = sinusoidal_pos_embed(t, time_embed_dim)
+    e = F.linear(e, sd[prefix + "time_embed.1.weight"], sd[prefix + "time_embed.1.bias"])
+    e = F.mish(e)
+    return F.linear(e, sd[prefix + "time_embed.3.weight"], sd[prefix + "time_embed.3.bias"])
+
+
+def flow_net_modulation(sd: SD, te: Tensor, layer: int, prefix: str = "flow_net."):
+    """simple_flow_net.py:27-30,41-42: Linear(H->3H)(SiLU(te)).view(B,3,H) -> gamma, scale, shift."""
+    p = f"{prefix}layers.{layer}.time_modulator.1."
+    m = F.linear(F.silu(te), sd[p + "weight"], sd[p + "bias"])
+    B = te.shape[0]
+    H = m.shape[1] // 3
+    gamma, scale, shift = m.view(B, 3, H).unbind(1)
+    return gamma, scale, shift
+
+
+def flow_net_layer(sd: SD, x: Tensor, te: Tensor, layer: int, prefix: str = "flow_net.") -> Tensor:
+    """FlowNetLayer.forward, simple_flow_net.py:39-48."""
+    gamma, scale, shift = flow_net_modulation(sd, te, layer, prefix)
+    H = x.shape[-1]
+    xn = F.layer_norm(x, (H,), None, None, 1e-6)           # :18 LayerNorm(no affine, eps=1e-6)
+    xn = xn.mul(scale.add(1)).add(shift)                   # :45
+    y = timm_mlp(xn, sd, f"{prefix}layers.{layer}.mlp.", gelu_tanh)
+    return x + y.mul(gamma)                                # :46
+
+
+def flow_net_forward(sd: SD, x: Tensor, t: Tensor, prefix: str = "flow_net.") -> Tensor:
+    """SimpleFlowNet.forward, simple_flow_net.py:99-108.  x (B,D), t (B,) -> v (B,D)."""
+    h = F.linear(x, sd[prefix + "input_proj.weight"], sd[prefix + "input_proj.bias"])
+    te = flow_net_time_embed(sd, t, prefix)
+    for l in range(flow_net_num_layers(sd, prefix)):
+        h = flow_net_layer(sd, h, te, l, prefix)
+    H = h.shape[-1]
+    h = F.layer_norm(h, (H,), sd[prefix + "norm.weight"], sd[prefix + "norm.bias"], 1e-5)  # :81
+    return F.linear(h, sd[prefix + "out_proj.weight"], sd[prefix + "out_proj.bias"])
+
+
+# ----------------------------------------------------------------------------------------
+# TorchFlowMatcher  (flare/flow/flow_matchers.py)
+# ----------------------------------------------------------------------------------------
+def euler_sample(sd: SD, x0: Tensor, num_steps: int, return_traces: bool = False,
+                 prefix: str = "flow_net."):
+    """TorchFlowMatcher.sample, flow_matchers.py:55-79 with `start` given.
+    dt = 1.0/K (python float); per step ts = ones(B) * (k/K); x = x + v*dt (mul, then add)."""
+    x = x0
+    dt = 1.0 / num_steps
+    traj = [x.clone()]
+    vel = []
+    for k in range(num_steps):
+        ts = torch.ones(x.shape[0], dtype=x.dtype) * (k / num_steps)
+        v = flow_net_forward(sd, x, ts, prefix)
+        x = x + v * dt
+        if return_traces:
+            traj.append(x.clone())
+            vel.append(v.clone())
+    if return_traces:
+        return x, (traj, vel)
+    return x
+
+
+def cfm_sample_location_and_conditional_flow(x0: Tensor, x1: Tensor, t: Tensor,
+                                             sigma: float = 0.0, eps: Tensor | None = None):
+    """torchcfm==1.0.5 ConditionalFlowMatcher.sample_location_and_conditional_flow
+    (RESTATED, UNPINNED; called at flow_matchers.py:34): mu_t = t*x1 + (1-t)*x0,
+    xt = mu_t + sigma*eps, ut = x1 - x0.  `t` (B,) and `eps` are explicit inputs here (the
+    reference draws them from the global torch RNG)."""
+    tt = t.reshape(-1, *([1] * (x0.dim() - 1)))
+    mu_t = tt * x1 + (1 - tt) * x0
+    xt = mu_t if (sigma == 0.0 or eps is None) else mu_t + sigma * eps
+    ut = x1 - x0
+    return t, xt, ut
+
+
+def fm_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, pair_i: Tensor | None = None,
+            pair_j: Tensor | None = None, sigma: float = 0.0, eps: Tensor | None = None,
+            prefix: str = "flow_net.") -> Tensor:
+    """TorchFlowMatcher.compute_loss, flow_matchers.py:19-39.  The exact-OT matcher re-pairs
+    (x0[i], x1[j]) from a minibatch OT plan before the CFM draw (torchcfm OTPlanSampler,
+    UNPINNED): the pairing is an explicit input (pair_i, pair_j); None = identity pairing,
+    which is the `conditional` matcher."""
+    x0, x1 = start, target
+    if pair_i is not None:
+        x0 = x0[pair_i]
+    if pair_j is not None:
+        x1 = x1[pair_j]
+    _, xt, ut = cfm_sample_location_and_conditional_flow(x0, x1, t, sigma, eps)
+    vt = flow_net_forward(sd, xt, t, prefix)
+    return torch.mean((vt - ut) ** 2)                      # :36
+
+
+# ----------------------------------------------------------------------------------------
+# encoders / decoder  (flare/networks/vita/action_ae.py, vita_policy.py:77)
+# ----------------------------------------------------------------------------------------
+def obs_encode(sd: SD, obs_features: Tensor) -> Tensor:
+    """vita_policy.py:77,114: nn.Linear(O, D)."""
+    return F.linear(obs_features, sd["obs_encoder.weight"], sd["obs_encoder.bias"])
+
+
+def cnn_action_encode(sd: SD, actions: Tensor, prefix: str = "action_encoder.") -> Tensor:
+    """CNNActionEncoder.forward, action_ae.py:318-327 (ctor :283-316): transpose ->
+    n x [Conv1d(k5,s2,p2)+ReLU] -> flatten -> latent_proj."""
+    B = actions.shape[0]
+    x = actions.transpose(1, 2)
+    i = 0
+    while f"{prefix}encoder.{i}.weight" in sd:
+        x = F.conv1d(x, sd[f"{prefix}encoder.{i}.weight"], sd[f"{prefix}encoder.{i}.bias"],
+                     stride=2, padding=2)
+        x = F.relu(x)
+        i += 2
+    x = x.reshape(B, -1)
+    return F.linear(x, sd[prefix + "latent_proj.weight"], sd[prefix + "latent_proj.bias"])
+
+
+def simple_action_encode(sd: SD, actions: Tensor, prefix: str = "action_encoder.") -> Tensor:
+    """SimpleActionEncoder.forward, action_ae.py:161-170 (non-attention branch)."""
+    B = actions.shape[0]
+    x = F.linear(actions, sd[prefix + "input_proj.weight"], sd[prefix + "input_proj.bias"])
+    i = 0
+    while f"{prefix}layers.{i}.fc1.weight" in sd:
+        x = timm_mlp(x, sd, f"{prefix}layers.{i}.", gelu_exact)
+        i += 1
+    return x.reshape(B, -1)
+
+
+def simple_action_decode(sd: SD, z: Tensor, pred_horizon: int, action_dim: int,
+                         prefix: str = "action_decoder.") -> Tensor:
+    """SimpleActionDecoder.forward, action_ae.py:267-279: input_proj; n x Mlp(exact GELU, no
+    residual, no norm); output_proj; view(B, T, A)."""
+    x = F.linear(z, sd[prefix + "input_proj.weight"], sd[prefix + "input_proj.bias"])
+    i = 0
+    while f"{prefix}layers.{i}.fc1.weight" in sd:
+        x = timm_mlp(x, sd, f"{prefix}layers.{i}.", gelu_exact)
+        i += 1
+    x = F.linear(x, sd[prefix + "output_proj.weight"], sd[prefix + "output_proj.bias"])
+    return x.view(-1, pred_horizon, action_dim)
+
+
+def action_encode(sd: SD, actions: Tensor) -> Tensor:
+    if "action_encoder.latent_proj.weight" in sd:
+        return cnn_action_encode(sd, actions)
+    return simple_action_encode(sd, actions)
+
+
+# ----------------------------------------------------------------------------------------
+# normalisation  (flare/utils/normalize.py)
+# ----------------------------------------------------------------------------------------
+def normalize(x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """Normalize.forward, normalize.py:38-46."""
+    return (x - mean) / (std + 1e-8)
+
+
+def unnormalize(x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """Unnormalize.forward, normalize.py:62-70."""
+    return x * std + mean
+
+
+# ----------------------------------------------------------------------------------------
+# losses
+# ----------------------------------------------------------------------------------------
+def contrastive_loss(image_features: Tensor, action_features: Tensor, temperature: float = 0.07):
+    """compute_contrastive_loss, contrastive_loss.py:5-22 (symmetric InfoNCE)."""
+    B = image_features.size(0)
+    a = F.normalize(image_features, dim=1)
+    b = F.normalize(action_features, dim=1)
+    logits = torch.matmul(a, b.T) / temperature
+    labels = torch.arange(B)
+    return (F.cross_entropy(logits, labels) + F.cross_entropy(logits.T, labels)) / 2
+
+
+def gaussian_kl(mean: Tensor, logvar: Tensor) -> Tensor:
+    """DiagonalGaussianDistribution.kl(other=None), dists.py:23-31, then `.mean()` as at
+    vita_policy.py:148."""
+    dims = list(range(1, mean.dim()))
+    kl = 0.5 * torch.sum(torch.pow(mean, 2) + torch.exp(logvar) - 1.0 - logvar, dim=dims)
+    return kl.mean()
+
+
+# ----------------------------------------------------------------------------------------
+# policy-level entry points  (flare/policies/vita/vita_policy.py)
+# ----------------------------------------------------------------------------------------
+def generate_actions(sd: SD, obs_features: Tensor, num_steps: int, pred_horizon: int,
+                     action_dim: int) -> Tensor:
+    """VitaPolicy.generate_actions, vita_policy.py:191-208, from observer features on:
+    obs_encoder -> FM.sample(start=obs_latents) -> action_decoder."""
+    z0 = obs_encode(sd, obs_features)
+    z = euler_sample(sd, z0, num_steps)
+    return simple_action_decode(sd, z, pred_horizon, action_dim)
+
+
+def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, num_steps: int,
+                 pair_i: Tensor | None = None, pair_j: Tensor | None = None,
+                 consistency_weight: float = 1.0, enc_recon_weight: float = 0.5,
+                 flow_recon_weight: float = 0.5, recon_loss_type: str = "l1",
+                 enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
+                 decode_flow_latents: bool = True, sigma: float = 0.0):
+    """VitaPolicy.compute_loss, vita_policy.py:112-189, from observer features on, with the
+    default non-variational, non-frozen autoencoder.  Returns (loss, metrics) where metrics
+    holds 0-dim tensors (the reference calls .item() on each)."""
+    recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
+    T, A = gt_actions.shape[1], gt_actions.shape[2]
+    B = obs_features.shape[0]
+    m = {}
+    obs_latents = obs_encode(sd, obs_features)                                  # :114
+    action_latents = action_encode(sd, gt_actions)                              # :123
+    flow_loss = fm_loss(sd, obs_latents, action_latents, t, pair_i, pair_j, sigma)  # :126-130
+    loss = flow_loss
+    m["flow_loss"] = flow_loss
+    if enc_contrastive_weight > 0:                                              # :134-139
+        c = contrastive_loss(obs_latents.view(B, -1), action_latents.view(B, -1))
+        loss = loss + enc_contrastive_weight * c
+        m["enc_contrastive_loss"] = c
+    if decode_flow_latents:                                                     # :153-178
+        pred = euler_sample(sd, obs_latents, num_steps)
+        if consistency_weight > 0:
+            c = F.mse_loss(pred, action_latents)
+            loss = loss + consistency_weight * c
+            m["consistency_loss"] = c
+        if flow_contrastive_weight > 0:
+            c = contrastive_loss(obs_latents.view(B, -1), pred.view(B, -1))
+            loss = loss + flow_contrastive_weight * c
+            m["flow_contrastive_loss"] = c
+        if flow_recon_weight > 0:
+            r = recon(simple_action_decode(sd, pred, T, A), gt_actions)
+            m["flow_action_recon_loss"] = r
+            loss = loss + flow_recon_weight * r
+    if enc_recon_weight > 0:                                                    # :183-187
+        r = recon(simple_action_decode(sd, action_latents, T, A), gt_actions)
+        m["enc_action_recon_loss"] = r
+        loss = loss + enc_recon_weight * r
+    m["loss"] = loss
+    return loss, m
+
+
+# ----------------------------------------------------------------------------------------
+# trainer tail  (flare/runners/policy_trainer.py:66-102; vita_policy.py:222-237)
+# ----------------------------------------------------------------------------------------
+def cosine_with_warmup_lambda(step: int, num_warmup_steps: int, num_training_steps: int,
+                              num_cycles: float = 0.5) -> float:
+    """diffusers==0.30.3 get_cosine_schedule_with_warmup lr_lambda (RESTATED, UNPINNED)."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+def ema_decay(optimization_step: int, max_decay: float = 0.9999, min_decay: float = 0.0,
+              inv_gamma: float = 1.0, power: float = 0.75, use_ema_warmup: bool = False) -> float:
+    """diffusers==0.30.3 EMAModel.get_decay (RESTATED, UNPINNED).  The reference passes only
+    `power` (base_policy.py:45-49) so use_ema_warmup is False and decay = (1+s)/(10+s)."""
+    step = max(0, optimization_step - 0 - 1)
+    if step <= 0:
+        return 0.0
+    if use_ema_warmup:
+        cur = 1 - (1 + step / inv_gamma) ** -power
+    else:
+        cur = (1 + step) / (10 + step)
+    return max(min(cur, max_decay), min_decay)
+
+
+def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
+               beta1: float = 0.95, beta2: float = 0.999, eps: float = 1e-8,
+               weight_decay: float = 1e-6):
+    """torch.optim.AdamW single-tensor update (the optimizer of vita_policy.py:222-229);
+    `step` is 1-based.  Updates p, m, v in place."""
+    p.mul_(1 - lr * weight_decay)
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+# ----------------------------------------------------------------------------------------
+# deterministic synthetic weights (shared by tests, smoke and bench; the product never
+# needs this: it takes whatever state dict the caller loads)
+# ----------------------------------------------------------------------------------------
+def make_state_dict(obs_dim: int, action_dim: int, latent_dim: int = 512, hidden_dim: int = 512,
+                    num_layers: int = 4, mlp_ratio: int = 4, pred_horizon: int = 16,
+                    ae_hidden: int = 512, ae_layers: int = 4, time_embed_dim: int = 256,
+                    encoder_type: str = "cnn", seed: int = 0, dtype=torch.float32) -> SD:
+    """Seeded Xavier-like weights with the reference's state-dict keys and shapes
+    (SURVEY.md 8(b)).  Biases and the modulators are NOT zero so every term is exercised."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def lin(name, out_f, in_f, gain=1.0, bias_std=0.02):
+        bound = gain * math.sqrt(6.0 / (in_f + out_f))
+        sd[name + ".weight"] = ((torch.rand(out_f, in_f, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+        sd[name + ".bias"] = (torch.randn(out_f, generator=g, dtype=torch.float64) * bias_std).to(dtype)
+
+    D, H, R = latent_dim, hidden_dim, mlp_ratio
+    lin("obs_encoder", D, obs_dim)
+    lin("flow_net.input_proj", H, D)
+    lin("flow_net.time_embed.1", time_embed_dim * 4, time_embed_dim)
+    lin("flow_net.time_embed.3", H, time_embed_dim * 4)
+    for l in range(num_layers):
+        lin(f"flow_net.layers.{l}.mlp.fc1", int(H * R), H)
+        lin(f"flow_net.layers.{l}.mlp.fc2", H, int(H * R))
+        lin(f"flow_net.layers.{l}.time_modulator.1", 3 * H, H, gain=0.5)
+    sd["flow_net.norm.weight"] = (1 + 0.1 * torch.randn(H, generator=g, dtype=torch.float64)).to(dtype)
+    sd["flow_net.norm.bias"] = (0.05 * torch.randn(H, generator=g, dtype=torch.float64)).to(dtype)
+    lin("flow_net.out_proj", D, H)
+    if encoder_type == "cnn":
+        cin = action_dim
+        for i in range(ae_layers):
+            fan_in, fan_out = cin * 5, ae_hidden * 5
+            bound = math.sqrt(6.0 / (fan_in + fan_out)) * 1.5
+            sd[f"action_encoder.encoder.{2*i}.weight"] = (
+                (torch.rand(ae_hidden, cin, 5, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+            sd[f"action_encoder.encoder.{2*i}.bias"] = (
+                torch.randn(ae_hidden, generator=g, dtype=torch.float64) * 0.02).to(dtype)
+            cin = ae_hidden
+        conv_len = pred_horizon // (2 ** ae_layers)
+        lin("action_encoder.latent_proj", D, ae_hidden * conv_len)
+    else:
+        ald = D // pred_horizon
+        lin("action_encoder.input_proj", ald, action_dim)
+        for i in range(ae_layers):
+            lin(f"action_encoder.layers.{i}.fc1", 4 * ald, ald)
+            lin(f"action_encoder.layers.{i}.fc2", ald, 4 * ald)
+    lin("action_decoder.input_proj", ae_hidden, D)
+    for i in range(ae_layers):
+        lin(f"action_decoder.layers.{i}.fc1", ae_hidden, ae_hidden)
+        lin(f"action_decoder.layers.{i}.fc2", ae_hidden, ae_hidden)
+    lin("action_decoder.output_proj", pred_horizon * action_dim, ae_hidden)
+    return sd
+
+
+def cast_sd(sd: SD, dtype) -> SD:
+    return {k: v.to(dtype) for k, v in sd.items()}
