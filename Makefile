@@ -1,0 +1,23 @@
+# Builds libvita_hip.so (gfx950 only) and the oracle's native pieces.  `make` cross-compiles
+# without a GPU; the .so is git-ignored but travels to the GPU box with the tree.
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+CSRC  := vita_amd/csrc
+SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_elementwise.hip
+HDRS  := $(CSRC)/vita_common.h include/vita_hip.h
+OBJS  := $(SRCS:.hip=.o)
+LIB   := vita_amd/libvita_hip.so
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -Wall -Wno-unused-function
+
+all: $(LIB)
+
+%.o: %.hip $(HDRS)
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(LIB): $(OBJS)
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -f $(OBJS) $(LIB)
+
+.PHONY: all clean

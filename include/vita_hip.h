@@ -1,0 +1,197 @@
+/* vita_hip.h — C ABI of libvita_hip.so: the MI355X (gfx950) kernels behind the VITA
+ * vision-latent -> action-latent flow-matching hot path.
+ *
+ * The reference (ucd-dare/VITA, /root/reference) is pure PyTorch and has no FFI of its own;
+ * every entry point below names the reference function whose arithmetic it replaces
+ * (file:line under /root/reference/flare).  INTEGRATION.md shows the ctypes binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *   - all tensor arguments are DEVICE pointers to fp32, row-major; `ld*` are row strides in
+ *     elements; weights keep the PyTorch nn.Linear layout (out_features, in_features), i.e.
+ *     the checkpoint tensors are passed as they are;
+ *   - `stream` is a hipStream_t (NULL = the default stream); every call only enqueues work on
+ *     it: no allocation, no synchronisation, no host<->device copy inside;
+ *   - scratch memory comes from the caller: ask vita_*_workspace_bytes(), pass a device
+ *     buffer at least that large and 256-byte aligned;
+ *   - return value 0 = ok, <0 = error (VITA_ERR_*); vita_last_error() gives the message of the
+ *     calling thread's last failure.  Shapes are validated on the host before any launch.
+ */
+#ifndef VITA_HIP_H
+#define VITA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITA_ABI_VERSION 1
+#define VITA_MAX_LAYERS 16
+
+typedef void* vita_stream_t; /* hipStream_t */
+
+enum { VITA_OK = 0, VITA_ERR_INVALID = -1, VITA_ERR_HIP = -2, VITA_ERR_WORKSPACE = -3 };
+
+/* activations fused into GEMM epilogues */
+enum {
+    VITA_ACT_NONE = 0,
+    VITA_ACT_RELU = 1,      /* CNNActionEncoder, action_ae.py:306 */
+    VITA_ACT_GELU_ERF = 2,  /* timm Mlp default act in SimpleActionDecoder/Encoder, action_ae.py:139-146,245-252 */
+    VITA_ACT_GELU_TANH = 3, /* FlowNetLayer approx_gelu, simple_flow_net.py:16 */
+    VITA_ACT_SILU = 4,      /* FlowNetLayer.time_modulator[0], simple_flow_net.py:28 */
+    VITA_ACT_MISH = 5       /* SimpleFlowNet.time_embed[2], simple_flow_net.py:69 */
+};
+
+/* A-operand prologues (applied while the activation tile is staged into LDS) */
+enum {
+    VITA_PRO_NONE = 0,
+    VITA_PRO_LN_MOD = 1,   /* LN(no affine) then x*(1+scale)+shift — simple_flow_net.py:44-45 */
+    VITA_PRO_LN_AFFINE = 2 /* LN then x*weight+bias — SimpleFlowNet.norm, simple_flow_net.py:81,106 */
+};
+
+int vita_abi_version(void);
+const char* vita_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * vita_linear_f32 — one fused dense layer on the fp32 MFMA path:
+ *     A'  = prologue(X)                                  (M,K)
+ *     Z   = act(A' · Wᵀ + bias)                          (M,N)
+ *     Y   = resid + Z * gate        when gate/gate_scalar/resid are given
+ * Replaces every nn.Linear (+ adjacent elementwise ops) on the path: obs_encoder
+ * (vita_policy.py:77,114), SimpleFlowNet.input_proj/out_proj and timm Mlp fc1/fc2
+ * (simple_flow_net.py:19-24,65,82,100-107), the time path (simple_flow_net.py:66-71,27-30),
+ * SimpleActionDecoder (action_ae.py:274-277) and CNNActionEncoder.latent_proj (:325).
+ * gate: per-column vector (ld_gate = 0, the sampling case) or per-row matrix (ld_gate > 0,
+ * per-row t in training): `x + mlp(x_norm).mul_(gamma)` simple_flow_net.py:46.  With
+ * use_gate_scalar the gate is the scalar `gate_scalar`: `x + vt*dt` flow_matchers.py:71.
+ * Y may alias resid.  Y must not alias X or W.
+ * --------------------------------------------------------------------------------------- */
+typedef struct vita_linear_args {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;          /* (N) or NULL */
+    float* Y; int64_t ldy;
+    int32_t M, N, K;
+    int32_t act;                /* VITA_ACT_* */
+    int32_t pro;                /* VITA_PRO_* ; LN runs over the whole K extent of a row */
+    float ln_eps;
+    const float* pro_mul; int64_t ld_pro_mul; /* (K) if ld==0 else (M,K): scale (LN_MOD) or weight (LN_AFFINE) */
+    const float* pro_add; int64_t ld_pro_add; /* shift / bias */
+    const float* gate; int64_t ld_gate;       /* NULL = none */
+    int32_t use_gate_scalar; float gate_scalar;
+    const float* resid; int64_t ld_resid;     /* NULL = none */
+} vita_linear_args;
+
+int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Weight descriptors: device pointers to the checkpoint tensors, unchanged.
+ * --------------------------------------------------------------------------------------- */
+typedef struct vita_flownet_weights { /* SimpleFlowNet, simple_flow_net.py:52-84 */
+    int32_t D;   /* input_dim = output_dim (latent) */
+    int32_t H;   /* hidden_dim */
+    int32_t FF;  /* int(H*mlp_ratio) */
+    int32_t L;   /* num_layers <= VITA_MAX_LAYERS */
+    int32_t TE;  /* time_embed_dim (256) */
+    const float *in_w, *in_b;     /* flow_net.input_proj   (H,D),(H) */
+    const float *te1_w, *te1_b;   /* flow_net.time_embed.1 (4TE,TE) */
+    const float *te3_w, *te3_b;   /* flow_net.time_embed.3 (H,4TE) */
+    const float *fc1_w[VITA_MAX_LAYERS], *fc1_b[VITA_MAX_LAYERS]; /* layers.l.mlp.fc1 (FF,H) */
+    const float *fc2_w[VITA_MAX_LAYERS], *fc2_b[VITA_MAX_LAYERS]; /* layers.l.mlp.fc2 (H,FF) */
+    const float *mod_w[VITA_MAX_LAYERS], *mod_b[VITA_MAX_LAYERS]; /* layers.l.time_modulator.1 (3H,H) */
+    const float *norm_w, *norm_b; /* flow_net.norm (H) */
+    const float *out_w, *out_b;   /* flow_net.out_proj (D,H) */
+} vita_flownet_weights;
+
+typedef struct vita_decoder_weights { /* SimpleActionDecoder, action_ae.py:226-279 */
+    int32_t D;    /* latent_dim */
+    int32_t HD;   /* dec_hidden_dim */
+    int32_t NL;   /* num_layers <= VITA_MAX_LAYERS */
+    int32_t OUT;  /* pred_horizon * action_dim */
+    const float *in_w, *in_b;   /* action_decoder.input_proj (HD,D) */
+    const float *fc1_w[VITA_MAX_LAYERS], *fc1_b[VITA_MAX_LAYERS]; /* layers.i.fc1 (HD,HD) */
+    const float *fc2_w[VITA_MAX_LAYERS], *fc2_b[VITA_MAX_LAYERS]; /* layers.i.fc2 (HD,HD) */
+    const float *out_w, *out_b; /* action_decoder.output_proj (OUT,HD) */
+} vita_decoder_weights;
+
+/* ---------------------------------------------------------------------------------------
+ * vita_flownet_forward_f32 — SimpleFlowNet.forward(x, t) with a per-row timestep
+ * (simple_flow_net.py:99-108; the training-time call at flow_matchers.py:35).
+ *   x (B,D), t (B) -> v (B,D).
+ * --------------------------------------------------------------------------------------- */
+size_t vita_flownet_forward_workspace_bytes(const vita_flownet_weights* w, int32_t B);
+int vita_flownet_forward_f32(const vita_flownet_weights* w, const float* x, int64_t ldx,
+                             const float* t, float* v, int64_t ldv, int32_t B,
+                             void* workspace, size_t workspace_bytes, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * vita_ode_sample_f32 — TorchFlowMatcher.sample with `start` given (flow_matchers.py:55-79):
+ * num_steps explicit Euler steps x <- x + v(x, k/K) * (1/K) over SimpleFlowNet, all enqueued by
+ * this one call.  The time path (sinusoid, time_embed, per-layer modulators) depends only on
+ * k, so it is evaluated once per call for all K steps as a (K, L, 3H) table.
+ *   x0 (B,D) -> x_out (B,D);  traj: NULL or (num_steps+1, B, D) receiving x_0..x_K
+ *   (return_traces=True, flow_matchers.py:63-66,73-75).  x_out may alias x0.
+ * --------------------------------------------------------------------------------------- */
+size_t vita_ode_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps);
+int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0,
+                        float* x_out, int64_t ldo, int32_t B, int32_t num_steps, float* traj,
+                        void* workspace, size_t workspace_bytes, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * vita_decoder_forward_f32 — SimpleActionDecoder.forward (action_ae.py:267-279):
+ *   z (B,D) -> actions (B, OUT) (the caller views it as (B,T,A)).
+ * --------------------------------------------------------------------------------------- */
+size_t vita_decoder_forward_workspace_bytes(const vita_decoder_weights* w, int32_t B);
+int vita_decoder_forward_f32(const vita_decoder_weights* w, const float* z, int64_t ldz,
+                             float* actions, int64_t lda, int32_t B,
+                             void* workspace, size_t workspace_bytes, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * vita_generate_actions_f32 — VitaPolicy.generate_actions from observer features on
+ * (vita_policy.py:191-208): obs_encoder (O->D), vita_ode_sample, decoder.  This is the
+ * quantity BasePolicy.validate times as chunks_per_sec (base_policy.py:65-87).
+ *   obs_features (B,O) -> actions (B, OUT);  latents_out: NULL or (B,D) receiving x_K.
+ * --------------------------------------------------------------------------------------- */
+size_t vita_generate_actions_workspace_bytes(const vita_flownet_weights* fw, const vita_decoder_weights* dw,
+                                             int32_t B, int32_t num_steps);
+int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O,
+                              const vita_flownet_weights* fw, const vita_decoder_weights* dw,
+                              const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                              float* latents_out, int32_t B, int32_t num_steps,
+                              void* workspace, size_t workspace_bytes, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Loss kernels (HBM-bound elementwise + two-stage deterministic reduction).
+ * `partials` is caller scratch of vita_loss_partials_count() floats; `out` is one device float.
+ * --------------------------------------------------------------------------------------- */
+int32_t vita_loss_partials_count(void);
+/* mean((a-b)^2): F.mse_loss (vita_policy.py:163) and torch.mean((vt-ut)**2) (flow_matchers.py:36) */
+int vita_mse_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream);
+/* grad_a = 2(a-b)/n * gout[0]; grad_b = -grad_a (either may be NULL) */
+int vita_mse_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout,
+                          float* grad_a, float* grad_b, vita_stream_t stream);
+/* mean(|a-b|): F.l1_loss (vita_policy.py:67,176,185) */
+int vita_l1_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream);
+/* grad_a = sign(a-b)/n * gout[0] */
+int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout,
+                         float* grad_a, float* grad_b, vita_stream_t stream);
+/* Fused CFM interpolation (torchcfm sample_location_and_conditional_flow, called at
+ * flow_matchers.py:34, sigma = 0): xt = t*x1 + (1-t)*x0, ut = x1 - x0, rows of x1 optionally
+ * gathered through pair_j (int64, the OT re-pairing; NULL = identity).  x0,x1,xt,ut (B,D); t (B). */
+int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_j,
+                             float* xt, float* ut, int32_t B, int32_t D, vita_stream_t stream);
+
+/* (x - mean) / (std + 1e-8) and x*std + mean over the last dim C, broadcast over rows:
+ * Normalize.forward / Unnormalize.forward, normalize.py:38-46,62-70. */
+int vita_normalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, vita_stream_t stream);
+int vita_unnormalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, vita_stream_t stream);
+
+/* Sinusoidal time embedding, pos_embed.py:11-18: t (B) -> (B, dim) = cat(sin(t f), cos(t f)). */
+int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B, int32_t dim, vita_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITA_HIP_H */

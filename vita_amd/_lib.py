@@ -1,0 +1,123 @@
+"""ctypes binding of libvita_hip.so (the C ABI declared in include/vita_hip.h).
+
+There is no fallback: if the shared library is missing or fails to load, importing the
+compute entry points raises — the product path never silently runs anything else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvita_hip.so")
+MAX_LAYERS = 16
+
+ACT_NONE, ACT_RELU, ACT_GELU_ERF, ACT_GELU_TANH, ACT_SILU, ACT_MISH = range(6)
+PRO_NONE, PRO_LN_MOD, PRO_LN_AFFINE = range(3)
+
+c_fp = C.c_void_p  # device pointers travel as integers
+
+
+class LinearArgs(C.Structure):
+    _fields_ = [
+        ("X", c_fp), ("ldx", C.c_int64),
+        ("W", c_fp), ("ldw", C.c_int64),
+        ("bias", c_fp),
+        ("Y", c_fp), ("ldy", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("act", C.c_int32), ("pro", C.c_int32), ("ln_eps", C.c_float),
+        ("pro_mul", c_fp), ("ld_pro_mul", C.c_int64),
+        ("pro_add", c_fp), ("ld_pro_add", C.c_int64),
+        ("gate", c_fp), ("ld_gate", C.c_int64),
+        ("use_gate_scalar", C.c_int32), ("gate_scalar", C.c_float),
+        ("resid", c_fp), ("ld_resid", C.c_int64),
+    ]
+
+
+_PA = c_fp * MAX_LAYERS
+
+
+class FlowNetWeights(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32), ("H", C.c_int32), ("FF", C.c_int32), ("L", C.c_int32), ("TE", C.c_int32),
+        ("in_w", c_fp), ("in_b", c_fp),
+        ("te1_w", c_fp), ("te1_b", c_fp),
+        ("te3_w", c_fp), ("te3_b", c_fp),
+        ("fc1_w", _PA), ("fc1_b", _PA),
+        ("fc2_w", _PA), ("fc2_b", _PA),
+        ("mod_w", _PA), ("mod_b", _PA),
+        ("norm_w", c_fp), ("norm_b", c_fp),
+        ("out_w", c_fp), ("out_b", c_fp),
+    ]
+
+
+class DecoderWeights(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32), ("HD", C.c_int32), ("NL", C.c_int32), ("OUT", C.c_int32),
+        ("in_w", c_fp), ("in_b", c_fp),
+        ("fc1_w", _PA), ("fc1_b", _PA),
+        ("fc2_w", _PA), ("fc2_b", _PA),
+        ("out_w", c_fp), ("out_b", c_fp),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
+SIGNATURES = {
+    "vita_abi_version": (C.c_int, []),
+    "vita_last_error": (C.c_char_p, []),
+    "vita_linear_f32": (C.c_int, [C.POINTER(LinearArgs), c_fp]),
+    "vita_flownet_forward_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.c_int32]),
+    "vita_flownet_forward_f32": (C.c_int, [C.POINTER(FlowNetWeights), c_fp, C.c_int64, c_fp, c_fp, C.c_int64,
+                                           C.c_int32, c_fp, C.c_size_t, c_fp]),
+    "vita_ode_sample_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.c_int32, C.c_int32]),
+    "vita_ode_sample_f32": (C.c_int, [C.POINTER(FlowNetWeights), c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32,
+                                      C.c_int32, c_fp, c_fp, C.c_size_t, c_fp]),
+    "vita_decoder_forward_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderWeights), C.c_int32]),
+    "vita_decoder_forward_f32": (C.c_int, [C.POINTER(DecoderWeights), c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32,
+                                           c_fp, C.c_size_t, c_fp]),
+    "vita_generate_actions_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
+                                                           C.c_int32, C.c_int32]),
+    "vita_generate_actions_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
+                                            c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int32, C.c_int32,
+                                            c_fp, C.c_size_t, c_fp]),
+    "vita_loss_partials_count": (C.c_int32, []),
+    "vita_mse_loss_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
+    "vita_mse_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
+    "vita_l1_loss_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
+    "vita_l1_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
+    "vita_cfm_interpolate_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
+    "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
+    "vita_sinusoidal_embed_f32": (C.c_int, [c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp]),
+}
+
+_lib = None
+
+
+class VitaHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libvita_hip.so and bind every symbol the header declares.  Raises if the
+    library has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VitaHipError(
+            f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()). "
+            "vita_amd has no CPU or PyTorch fallback on purpose.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = ABI mismatch; let it surface
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().vita_last_error()
+        raise VitaHipError(f"{what} failed (rc={rc}): {msg.decode() if msg else '?'}")

@@ -1,0 +1,291 @@
+// C-ABI entry points that chain the fused GEMM kernels into the reference's operators:
+// SimpleFlowNet.forward, TorchFlowMatcher.sample, SimpleActionDecoder.forward and
+// VitaPolicy.generate_actions.  Host code only validates shapes, carves the caller's
+// workspace and enqueues launches on the caller's stream.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "vita_common.h"
+
+namespace vita {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int gemm_f32(const vita_linear_args& a, hipStream_t stream);
+int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
+int launch_step_times(float* ts, int K, hipStream_t s);
+
+// ---- workspace carving -------------------------------------------------------------------
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    float* take(size_t nfloats) {
+        float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += (nfloats * sizeof(float) + 255) & ~size_t(255);
+        return r;
+    }
+};
+
+struct FlowWs {
+    float *ts, *sin, *hid, *silu, *mod, *h, *u, *x;
+    size_t bytes;
+};
+// T = number of distinct timesteps (num_steps when sampling, B for per-row t)
+static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, bool need_x) {
+    Carver c(ws);
+    FlowWs f;
+    f.ts = c.take((size_t)T);
+    f.sin = c.take((size_t)T * w->TE);
+    f.hid = c.take((size_t)T * 4 * w->TE);
+    f.silu = c.take((size_t)T * w->H);
+    f.mod = c.take((size_t)T * w->L * 3 * w->H);
+    f.h = c.take((size_t)B * w->H);
+    f.u = c.take((size_t)B * w->FF);
+    f.x = need_x ? c.take((size_t)B * w->D) : nullptr;
+    f.bytes = c.off;
+    return f;
+}
+
+static int check_flow_weights(const vita_flownet_weights* w, const char* who) {
+    VITA_REQUIRE(w != nullptr, "%s: null weights", who);
+    VITA_REQUIRE(w->D > 0 && w->H > 0 && w->FF > 0 && w->TE >= 4 && w->TE % 2 == 0,
+                 "%s: bad dims D=%d H=%d FF=%d TE=%d", who, w->D, w->H, w->FF, w->TE);
+    VITA_REQUIRE(w->L >= 0 && w->L <= VITA_MAX_LAYERS, "%s: L=%d outside [0,%d]", who, w->L, VITA_MAX_LAYERS);
+    VITA_REQUIRE(w->in_w && w->in_b && w->te1_w && w->te1_b && w->te3_w && w->te3_b && w->norm_w && w->norm_b && w->out_w &&
+                     w->out_b,
+                 "%s: null weight pointer", who);
+    for (int l = 0; l < w->L; ++l)
+        VITA_REQUIRE(w->fc1_w[l] && w->fc1_b[l] && w->fc2_w[l] && w->fc2_b[l] && w->mod_w[l] && w->mod_b[l],
+                     "%s: null weight pointer in layer %d", who, l);
+    return VITA_OK;
+}
+
+static vita_linear_args lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* b, float* Y, int64_t ldy, int M,
+                            int N, int K, int act) {
+    vita_linear_args a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = b; a.Y = Y; a.ldy = ldy;
+    a.M = M; a.N = N; a.K = K; a.act = act;
+    return a;
+}
+
+#define VITA_TRY(expr)              \
+    do {                            \
+        int rc__ = (expr);          \
+        if (rc__ != VITA_OK) return rc__; \
+    } while (0)
+
+// Time path for T timesteps already in f.ts: sinusoid -> Linear+Mish -> Linear (+SiLU, the only
+// form the modulators consume) -> per-layer modulator Linear into f.mod (T, L, 3H).
+// simple_flow_net.py:66-71 and :27-30,41.
+static int time_path(const vita_flownet_weights* w, const FlowWs& f, int T, hipStream_t s) {
+    const int TE = w->TE, H = w->H, L = w->L;
+    VITA_TRY(launch_sinusoid(f.ts, f.sin, TE, T, TE, s));
+    VITA_TRY(gemm_f32(lin(f.sin, TE, w->te1_w, TE, w->te1_b, f.hid, 4 * TE, T, 4 * TE, TE, VITA_ACT_MISH), s));
+    VITA_TRY(gemm_f32(lin(f.hid, 4 * TE, w->te3_w, 4 * TE, w->te3_b, f.silu, H, T, H, 4 * TE, VITA_ACT_SILU), s));
+    for (int l = 0; l < L; ++l)
+        VITA_TRY(gemm_f32(lin(f.silu, H, w->mod_w[l], H, w->mod_b[l], f.mod + (size_t)l * 3 * H, (int64_t)L * 3 * H, T, 3 * H, H,
+                              VITA_ACT_NONE), s));
+    return VITA_OK;
+}
+
+// One velocity-field evaluation given the modulation rows.
+//   mod: pointer to this evaluation's (gamma|scale|shift) block of layer 0; ld_mod = 0 when the
+//   same row serves the whole batch (sampling), L*3H when each row has its own t (training).
+//   Output: Y = resid + gate_scalar * v   when resid != NULL (the Euler update, flow_matchers.py:71)
+//           Y = v                          otherwise.
+static int flow_eval(const vita_flownet_weights* w, const FlowWs& f, const float* x, int64_t ldx, const float* mod, int64_t ld_mod,
+                     float* Y, int64_t ldy, const float* resid, int64_t ld_resid, float dt, int B, hipStream_t s) {
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L;
+    VITA_TRY(gemm_f32(lin(x, ldx, w->in_w, D, w->in_b, f.h, H, B, H, D, VITA_ACT_NONE), s));        // :100
+    for (int l = 0; l < L; ++l) {
+        const float* gamma = mod + (size_t)l * 3 * H;
+        const float* scale = gamma + H;
+        const float* shift = gamma + 2 * H;
+        vita_linear_args a = lin(f.h, H, w->fc1_w[l], H, w->fc1_b[l], f.u, FF, B, FF, H, VITA_ACT_GELU_TANH);
+        a.pro = VITA_PRO_LN_MOD; a.ln_eps = 1e-6f;                                                    // :18,44-45
+        a.pro_mul = scale; a.ld_pro_mul = ld_mod; a.pro_add = shift; a.ld_pro_add = ld_mod;
+        VITA_TRY(gemm_f32(a, s));
+        vita_linear_args b = lin(f.u, FF, w->fc2_w[l], FF, w->fc2_b[l], f.h, H, B, H, FF, VITA_ACT_NONE);
+        b.gate = gamma; b.ld_gate = ld_mod; b.resid = f.h; b.ld_resid = H;                            // :46
+        VITA_TRY(gemm_f32(b, s));
+    }
+    vita_linear_args o = lin(f.h, H, w->out_w, H, w->out_b, Y, ldy, B, D, H, VITA_ACT_NONE);
+    o.pro = VITA_PRO_LN_AFFINE; o.ln_eps = 1e-5f;                                                     // :81,106-107
+    o.pro_mul = w->norm_w; o.ld_pro_mul = 0; o.pro_add = w->norm_b; o.ld_pro_add = 0;
+    if (resid) { o.use_gate_scalar = 1; o.gate_scalar = dt; o.resid = resid; o.ld_resid = ld_resid; }
+    VITA_TRY(gemm_f32(o, s));
+    return VITA_OK;
+}
+
+static int check_ws(const void* ws, size_t have, size_t need, const char* who) {
+    if (need == 0) return VITA_OK;
+    if (ws == nullptr || have < need) {
+        set_error("%s: workspace too small or null (have %zu bytes, need %zu)", who, have, need);
+        return VITA_ERR_WORKSPACE;
+    }
+    if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) {
+        set_error("%s: workspace must be 256-byte aligned", who);
+        return VITA_ERR_WORKSPACE;
+    }
+    return VITA_OK;
+}
+
+static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
+                      float* traj, void* ws, hipStream_t s) {
+    const int D = w->D, H = w->H, L = w->L;
+    FlowWs f = carve_flow(ws, w, B, K, false);
+    VITA_TRY(launch_step_times(f.ts, K, s));
+    VITA_TRY(time_path(w, f, K, s));
+    const float dt = (float)(1.0 / (double)K);  // python float 1.0/num_steps, rounded to fp32 at the multiply
+    if (traj)
+        VITA_CHECK_HIP(hipMemcpy2DAsync(traj, (size_t)D * 4, x0, (size_t)ldx0 * 4, (size_t)D * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
+    const float* src = x0;
+    int64_t lds = ldx0;
+    for (int k = 0; k < K; ++k) {
+        float* dst = traj ? traj + (size_t)(k + 1) * B * D : x_out;
+        const int64_t ldd = traj ? D : ldo;
+        const float* mod = f.mod + (size_t)k * L * 3 * H;
+        VITA_TRY(flow_eval(w, f, src, lds, mod, 0, dst, ldd, src, lds, dt, B, s));
+        src = dst;
+        lds = ldd;
+    }
+    if (traj)
+        VITA_CHECK_HIP(hipMemcpy2DAsync(x_out, (size_t)ldo * 4, src, (size_t)D * 4, (size_t)D * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
+    return VITA_OK;
+}
+
+struct DecWs { float *a, *b; size_t bytes; };
+static DecWs carve_dec(void* ws, const vita_decoder_weights* w, int B) {
+    Carver c(ws);
+    DecWs d;
+    d.a = c.take((size_t)B * w->HD);
+    d.b = c.take((size_t)B * w->HD);
+    d.bytes = c.off;
+    return d;
+}
+static int check_dec_weights(const vita_decoder_weights* w, const char* who) {
+    VITA_REQUIRE(w != nullptr, "%s: null decoder weights", who);
+    VITA_REQUIRE(w->D > 0 && w->HD > 0 && w->OUT > 0 && w->NL >= 0 && w->NL <= VITA_MAX_LAYERS, "%s: bad decoder dims", who);
+    VITA_REQUIRE(w->in_w && w->in_b && w->out_w && w->out_b, "%s: null decoder weight pointer", who);
+    for (int i = 0; i < w->NL; ++i)
+        VITA_REQUIRE(w->fc1_w[i] && w->fc1_b[i] && w->fc2_w[i] && w->fc2_b[i], "%s: null decoder weight pointer in layer %d", who, i);
+    return VITA_OK;
+}
+static int decoder_forward(const vita_decoder_weights* w, const float* z, int64_t ldz, float* out, int64_t ldo, int B, void* ws,
+                           hipStream_t s) {
+    const int D = w->D, HD = w->HD;
+    DecWs d = carve_dec(ws, w, B);
+    VITA_TRY(gemm_f32(lin(z, ldz, w->in_w, D, w->in_b, d.a, HD, B, HD, D, VITA_ACT_NONE), s));           // action_ae.py:274
+    for (int i = 0; i < w->NL; ++i) {                                                                     // :275-276
+        VITA_TRY(gemm_f32(lin(d.a, HD, w->fc1_w[i], HD, w->fc1_b[i], d.b, HD, B, HD, HD, VITA_ACT_GELU_ERF), s));
+        VITA_TRY(gemm_f32(lin(d.b, HD, w->fc2_w[i], HD, w->fc2_b[i], d.a, HD, B, HD, HD, VITA_ACT_NONE), s));
+    }
+    VITA_TRY(gemm_f32(lin(d.a, HD, w->out_w, HD, w->out_b, out, ldo, B, w->OUT, HD, VITA_ACT_NONE), s)); // :277
+    return VITA_OK;
+}
+
+}  // namespace vita
+
+using namespace vita;
+
+extern "C" {
+
+int vita_abi_version(void) { return VITA_ABI_VERSION; }
+const char* vita_last_error(void) { return g_err; }
+
+int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream) {
+    VITA_REQUIRE(args != nullptr, "vita_linear_f32: null args");
+    return gemm_f32(*args, (hipStream_t)stream);
+}
+
+size_t vita_flownet_forward_workspace_bytes(const vita_flownet_weights* w, int32_t B) {
+    if (!w || B <= 0) return 0;
+    return carve_flow(nullptr, w, B, B, false).bytes;
+}
+
+int vita_flownet_forward_f32(const vita_flownet_weights* w, const float* x, int64_t ldx, const float* t, float* v, int64_t ldv,
+                             int32_t B, void* workspace, size_t workspace_bytes, vita_stream_t stream) {
+    VITA_TRY(check_flow_weights(w, "vita_flownet_forward_f32"));
+    VITA_REQUIRE(B >= 0, "vita_flownet_forward_f32: B < 0");
+    if (B == 0) return VITA_OK;
+    VITA_REQUIRE(x && t && v && ldx >= w->D && ldv >= w->D, "vita_flownet_forward_f32: bad x/t/v");
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_flownet_forward_workspace_bytes(w, B), "vita_flownet_forward_f32"));
+    hipStream_t s = (hipStream_t)stream;
+    FlowWs f = carve_flow(workspace, w, B, B, false);
+    VITA_CHECK_HIP(hipMemcpyAsync(f.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
+    VITA_TRY(time_path(w, f, B, s));
+    return flow_eval(w, f, x, ldx, f.mod, (int64_t)w->L * 3 * w->H, v, ldv, nullptr, 0, 0.f, B, s);
+}
+
+size_t vita_ode_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {
+    if (!w || B <= 0 || num_steps <= 0) return 0;
+    return carve_flow(nullptr, w, B, num_steps, false).bytes;
+}
+
+int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
+                        int32_t num_steps, float* traj, void* workspace, size_t workspace_bytes, vita_stream_t stream) {
+    VITA_TRY(check_flow_weights(w, "vita_ode_sample_f32"));
+    VITA_REQUIRE(num_steps >= 1, "vita_ode_sample_f32: num_steps must be >= 1 (got %d)", num_steps);
+    VITA_REQUIRE(B >= 0, "vita_ode_sample_f32: B < 0");
+    if (B == 0) return VITA_OK;
+    VITA_REQUIRE(x0 && x_out && ldx0 >= w->D && ldo >= w->D, "vita_ode_sample_f32: bad x0/x_out");
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_ode_sample_workspace_bytes(w, B, num_steps), "vita_ode_sample_f32"));
+    return ode_sample(w, x0, ldx0, x_out, ldo, B, num_steps, traj, workspace, (hipStream_t)stream);
+}
+
+size_t vita_decoder_forward_workspace_bytes(const vita_decoder_weights* w, int32_t B) {
+    if (!w || B <= 0) return 0;
+    return carve_dec(nullptr, w, B).bytes;
+}
+
+int vita_decoder_forward_f32(const vita_decoder_weights* w, const float* z, int64_t ldz, float* actions, int64_t lda, int32_t B,
+                             void* workspace, size_t workspace_bytes, vita_stream_t stream) {
+    VITA_TRY(check_dec_weights(w, "vita_decoder_forward_f32"));
+    VITA_REQUIRE(B >= 0, "vita_decoder_forward_f32: B < 0");
+    if (B == 0) return VITA_OK;
+    VITA_REQUIRE(z && actions && ldz >= w->D && lda >= w->OUT, "vita_decoder_forward_f32: bad z/actions");
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_decoder_forward_workspace_bytes(w, B), "vita_decoder_forward_f32"));
+    return decoder_forward(w, z, ldz, actions, lda, B, workspace, (hipStream_t)stream);
+}
+
+size_t vita_generate_actions_workspace_bytes(const vita_flownet_weights* fw, const vita_decoder_weights* dw, int32_t B,
+                                             int32_t num_steps) {
+    if (!fw || !dw || B <= 0 || num_steps <= 0) return 0;
+    const size_t lat = ((size_t)B * fw->D * 4 + 255) & ~size_t(255);
+    const size_t a = carve_flow(nullptr, fw, B, num_steps, false).bytes;
+    const size_t b = carve_dec(nullptr, dw, B).bytes;
+    return lat + (a > b ? a : b);
+}
+
+int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O, const vita_flownet_weights* fw,
+                              const vita_decoder_weights* dw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                              float* latents_out, int32_t B, int32_t num_steps, void* workspace, size_t workspace_bytes,
+                              vita_stream_t stream) {
+    VITA_TRY(check_flow_weights(fw, "vita_generate_actions_f32"));
+    VITA_TRY(check_dec_weights(dw, "vita_generate_actions_f32"));
+    VITA_REQUIRE(fw->D == dw->D, "vita_generate_actions_f32: flow-net D=%d != decoder D=%d", fw->D, dw->D);
+    VITA_REQUIRE(num_steps >= 1, "vita_generate_actions_f32: num_steps must be >= 1 (got %d)", num_steps);
+    VITA_REQUIRE(B >= 0 && O > 0, "vita_generate_actions_f32: bad B/O");
+    if (B == 0) return VITA_OK;
+    VITA_REQUIRE(obs_w && obs_b && obs_features && actions && ldobs >= O && lda >= dw->OUT, "vita_generate_actions_f32: bad pointers/strides");
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_generate_actions_workspace_bytes(fw, dw, B, num_steps), "vita_generate_actions_f32"));
+    hipStream_t s = (hipStream_t)stream;
+    const int D = fw->D;
+    float* lat = static_cast<float*>(workspace);
+    char* rest = static_cast<char*>(workspace) + (((size_t)B * D * 4 + 255) & ~size_t(255));
+    VITA_TRY(gemm_f32(lin(obs_features, ldobs, obs_w, O, obs_b, lat, D, B, D, O, VITA_ACT_NONE), s));  // vita_policy.py:194
+    VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s));                           // :196-203
+    if (latents_out)
+        VITA_CHECK_HIP(hipMemcpyAsync(latents_out, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s));
+    return decoder_forward(dw, lat, D, actions, lda, B, rest, s);                                       // :206
+}
+
+}  // extern "C"

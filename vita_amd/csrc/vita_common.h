@@ -1,0 +1,71 @@
+// Shared device helpers for the VITA hot-path kernels (gfx950 / CDNA4 only).
+// Compiled with -ffp-contract=off: every FMA in this tree is written explicitly so the op
+// order of the reference (e.g. `x + v*dt`: multiply, round, add — flow_matchers.py:71) is kept.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/vita_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace vita {
+
+void set_error(const char* fmt, ...);
+
+#define VITA_CHECK_HIP(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            vita::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return VITA_ERR_HIP;                                                          \
+        }                                                                                 \
+    } while (0)
+
+#define VITA_REQUIRE(cond, ...)                                                           \
+    do {                                                                                  \
+        if (!(cond)) {                                                                    \
+            vita::set_error(__VA_ARGS__);                                                 \
+            return VITA_ERR_INVALID;                                                      \
+        }                                                                                 \
+    } while (0)
+
+// ---- activations (fp32, accurate to a few ulp of the output scale) ----------------------
+// 0.5*(1+tanh(u)) == 1/(1+exp(-2u)); avoids the cancellation of the tanh form and costs one
+// v_exp_f32 + one division.  PyTorch: GeluKernel "tanh" approximation constants.
+__device__ __forceinline__ float act_gelu_tanh(float x) {
+    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
+    const float kKappa = 0.044715f;
+    float x3 = x * x * x;
+    float inner = kBeta * (x + kKappa * x3);
+    float e = __expf(-2.0f * inner);
+    return x / (1.0f + e);
+}
+__device__ __forceinline__ float act_gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+__device__ __forceinline__ float act_silu(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float act_mish(float x) {
+    // x * tanh(softplus(x)), softplus threshold 20 as in torch.
+    float sp = x > 20.0f ? x : log1pf(expf(x));
+    return x * tanhf(sp);
+}
+__device__ __forceinline__ float apply_act(float x, int act) {
+    switch (act) {
+        case VITA_ACT_RELU: return x > 0.0f ? x : 0.0f;
+        case VITA_ACT_GELU_ERF: return act_gelu_erf(x);
+        case VITA_ACT_GELU_TANH: return act_gelu_tanh(x);
+        case VITA_ACT_SILU: return act_silu(x);
+        case VITA_ACT_MISH: return act_mish(x);
+        default: return x;
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+}  // namespace vita

@@ -1,0 +1,239 @@
+// HBM-bound elementwise / reduction kernels of the VITA hot path: losses and their backward,
+// CFM interpolation, (un)normalisation, sinusoidal time embedding.
+// All are grid-stride, 16-byte vectorised where alignment allows, wave64 shuffle reductions,
+// and reduce in two deterministic stages (per-block partial -> one-block final) so a loss
+// value is bitwise reproducible run to run (no float atomics).
+#include "vita_common.h"
+
+namespace vita {
+
+constexpr int EW_THREADS = 256;
+constexpr int LOSS_BLOCKS = 1024;  // = vita_loss_partials_count()
+
+static inline int ew_grid(int64_t work_items, int cap = 2048) {
+    int64_t b = (work_items + EW_THREADS - 1) / EW_THREADS;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return (int)b;
+}
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// ---- stage 1: per-block partial of sum f(a-b) ---------------------------------------------
+template <bool L1>
+__global__ __launch_bounds__(EW_THREADS) void diff_reduce_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                               int64_t n, int vec, float* __restrict__ partials) {
+    float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+    const int64_t gid = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x;
+    if (vec) {
+        const int64_t n4 = n >> 2;
+        const f32x4* a4 = reinterpret_cast<const f32x4*>(a);
+        const f32x4* b4 = reinterpret_cast<const f32x4*>(b);
+        for (int64_t i = gid; i < n4; i += stride) {
+            const f32x4 x = a4[i], y = b4[i];
+            float t = 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = x[j] - y[j];
+                t += L1 ? fabsf(d) : d * d;
+            }
+            s += t;
+        }
+        for (int64_t i = (n4 << 2) + gid; i < n; i += stride) {
+            const float d = a[i] - b[i];
+            s += L1 ? fabsf(d) : d * d;
+        }
+    } else {
+        for (int64_t i = gid; i < n; i += stride) {
+            const float d = a[i] - b[i];
+            s += L1 ? fabsf(d) : d * d;
+        }
+    }
+    s = wave_sum(s);
+    __shared__ float ws[EW_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < EW_THREADS / 64; ++i) t += ws[i];
+        partials[blockIdx.x] = t;
+    }
+}
+
+// ---- stage 2: one block folds the partials in double, divides by n -------------------------
+__global__ __launch_bounds__(EW_THREADS) void finalize_mean_kernel(const float* __restrict__ partials, int count, int64_t n,
+                                                                 float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += EW_THREADS) s += (double)partials[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[EW_THREADS / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int i = 0; i < EW_THREADS / 64; ++i) t += ws[i];
+        out[0] = (float)(t / (double)n);
+    }
+}
+
+template <bool L1>
+__global__ __launch_bounds__(EW_THREADS) void diff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                            const float* __restrict__ gout, float* __restrict__ ga,
+                                                            float* __restrict__ gb) {
+    const float g = gout[0];
+    const float inv_n = 1.0f / (float)n;
+    const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const float d = a[i] - b[i];
+        float v;
+        if (L1) v = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n * g;   // sign(d)/n * gout
+        else v = (2.0f * d) * inv_n * g;                                    // 2 d / n * gout
+        if (ga) ga[i] = v;
+        if (gb) gb[i] = -v;
+    }
+}
+
+template <bool L1>
+static int loss_fwd(const float* a, const float* b, int64_t n, float* partials, float* out, hipStream_t s, const char* name) {
+    VITA_REQUIRE(a && b && partials && out, "%s: null pointer", name);
+    VITA_REQUIRE(n > 0, "%s: n must be > 0 (got %lld); the mean of an empty tensor is undefined", name, (long long)n);
+    const int vec = al16(a) && al16(b);
+    const int blocks = ew_grid((n + 3) / 4, LOSS_BLOCKS);
+    hipLaunchKernelGGL((diff_reduce_kernel<L1>), dim3(blocks), dim3(EW_THREADS), 0, s, a, b, n, vec, partials);
+    hipLaunchKernelGGL(finalize_mean_kernel, dim3(1), dim3(EW_THREADS), 0, s, partials, blocks, n, out);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+template <bool L1>
+static int loss_bwd(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, hipStream_t s,
+                    const char* name) {
+    VITA_REQUIRE(a && b && gout, "%s: null pointer", name);
+    VITA_REQUIRE(n > 0, "%s: n must be > 0", name);
+    if (!ga && !gb) return VITA_OK;
+    hipLaunchKernelGGL((diff_bwd_kernel<L1>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, n, gout, ga, gb);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+// ---- CFM interpolation ---------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void cfm_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                       const float* __restrict__ t, const int64_t* __restrict__ pj,
+                                                       float* __restrict__ xt, float* __restrict__ ut, int B, int D) {
+    const int64_t n = (int64_t)B * D;
+    const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const int64_t r1 = pj ? pj[r] : r;
+        const float a = x0[i], b = x1[r1 * D + c], tt = t[r];
+        xt[i] = tt * b + (1.0f - tt) * a;   // torchcfm: t*x1 + (1-t)*x0  (sigma = 0)
+        ut[i] = b - a;
+    }
+}
+
+// ---- (un)normalise ---------------------------------------------------------------------------
+template <bool UN>
+__global__ __launch_bounds__(EW_THREADS) void norm_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                                        const float* __restrict__ sd, float* __restrict__ y, int64_t n, int C) {
+    const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % C);
+        if (UN) y[i] = x[i] * sd[c] + mean[c];
+        else y[i] = (x[i] - mean[c]) / (sd[c] + 1e-8f);
+    }
+}
+
+// ---- sinusoidal embedding --------------------------------------------------------------------
+__global__ __launch_bounds__(EW_THREADS) void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int64_t ldo,
+                                                            int B, int dim) {
+    const int half = dim / 2;
+    const float emb = logf(10000.0f) / (float)(half - 1);
+    const int64_t n = (int64_t)B * half;
+    const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / half), j = (int)(i - (int64_t)r * half);
+        const float f = expf((float)j * -emb);
+        const float e = t[r] * f;
+        out[r * ldo + j] = sinf(e);
+        out[r * ldo + half + j] = cosf(e);
+    }
+}
+
+// step times k/K for the sampler: ts[k] = 1.0f * (float)(k / K)  (flow_matchers.py:69)
+__global__ void step_times_kernel(float* __restrict__ ts, int K) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < K) ts[k] = (float)((double)k / (double)K);
+}
+
+int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s) {
+    VITA_REQUIRE(t && out, "vita_sinusoidal_embed_f32: null pointer");
+    VITA_REQUIRE(dim >= 4 && dim % 2 == 0 && ldo >= dim, "vita_sinusoidal_embed_f32: dim must be even and >= 4, ldo >= dim");
+    if (B <= 0) return VITA_OK;
+    hipLaunchKernelGGL(sinusoid_kernel, dim3(ew_grid((int64_t)B * (dim / 2))), dim3(EW_THREADS), 0, s, t, out, ldo, B, dim);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+int launch_step_times(float* ts, int K, hipStream_t s) {
+    hipLaunchKernelGGL(step_times_kernel, dim3((K + 63) / 64), dim3(64), 0, s, ts, K);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+}  // namespace vita
+
+using namespace vita;
+
+extern "C" {
+
+int32_t vita_loss_partials_count(void) { return LOSS_BLOCKS; }
+
+int vita_mse_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream) {
+    return loss_fwd<false>(a, b, n, partials, out, (hipStream_t)stream, "vita_mse_loss_fwd_f32");
+}
+int vita_l1_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream) {
+    return loss_fwd<true>(a, b, n, partials, out, (hipStream_t)stream, "vita_l1_loss_fwd_f32");
+}
+int vita_mse_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, vita_stream_t stream) {
+    return loss_bwd<false>(a, b, n, gout, ga, gb, (hipStream_t)stream, "vita_mse_loss_bwd_f32");
+}
+int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, vita_stream_t stream) {
+    return loss_bwd<true>(a, b, n, gout, ga, gb, (hipStream_t)stream, "vita_l1_loss_bwd_f32");
+}
+
+int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_j, float* xt, float* ut,
+                             int32_t B, int32_t D, vita_stream_t stream) {
+    VITA_REQUIRE(x0 && x1 && t && xt && ut, "vita_cfm_interpolate_f32: null pointer");
+    VITA_REQUIRE(B >= 0 && D > 0, "vita_cfm_interpolate_f32: bad shape B=%d D=%d", B, D);
+    if (B == 0) return VITA_OK;
+    hipLaunchKernelGGL(cfm_kernel, dim3(ew_grid((int64_t)B * D)), dim3(EW_THREADS), 0, (hipStream_t)stream, x0, x1, t, pair_j, xt,
+                       ut, B, D);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+int vita_normalize_f32(const float* x, const float* mean, const float* sd, float* y, int64_t rows, int32_t C, vita_stream_t stream) {
+    VITA_REQUIRE(x && mean && sd && y, "vita_normalize_f32: null pointer");
+    VITA_REQUIRE(rows >= 0 && C > 0, "vita_normalize_f32: bad shape");
+    if (rows == 0) return VITA_OK;
+    hipLaunchKernelGGL((norm_kernel<false>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, mean, sd, y,
+                       rows * C, C);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+int vita_unnormalize_f32(const float* x, const float* mean, const float* sd, float* y, int64_t rows, int32_t C, vita_stream_t stream) {
+    VITA_REQUIRE(x && mean && sd && y, "vita_unnormalize_f32: null pointer");
+    VITA_REQUIRE(rows >= 0 && C > 0, "vita_unnormalize_f32: bad shape");
+    if (rows == 0) return VITA_OK;
+    hipLaunchKernelGGL((norm_kernel<true>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, mean, sd, y,
+                       rows * C, C);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B, int32_t dim, vita_stream_t stream) {
+    return launch_sinusoid(t, out, ldo, B, dim, (hipStream_t)stream);
+}
+
+}  // extern "C"
