@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py — ODE action-chunks/sec of the VITA hot path on MI355X.
+
+A "step" is one pass of `VitaPolicy.generate_actions` from observer features on
+(obs_encoder -> K-step Euler ODE over SimpleFlowNet -> action decoder, vita_policy.py:191-208)
+over one batch of synthetic hook_package-shaped input already resident in HBM: B=4096 rows per
+GPU, O=533, D=H=512, L=4, R=4, K=6, T*A=336, fp32 (BASELINE.json configs[1]).  With N>1 every
+rank runs its own 4096-row shard (rows are independent: no collective on the data path) and the
+value is the sum over ranks divided by the slowest rank's time (weak scaling).
+
+Contract: python bench.py --gpus N --steps K --warmup W  ->  ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+# algorithmic FLOPs (2*M*N*K, x-dependent GEMMs only; SURVEY.md 8(d) / BASELINE.md section 4)
+def flops_per_chunk(O, D, H, FF, L, K, HD, NL, OUT):
+    f_step = 2 * D * H + L * (2 * H * FF + 2 * FF * H) + 2 * H * D
+    f_dec = 2 * D * HD + NL * (2 * 2 * HD * HD) + 2 * HD * OUT
+    return 2 * O * D + K * f_step + f_dec
+
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
+TASKS = {"hook_package": (533, 21), "robomimic_square": (555, 7), "pusht": (514, 2), "thread_needle": (533, 21)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="rows per GPU")
+    ap.add_argument("--ode-steps", type=int, default=6)
+    ap.add_argument("--task", default="hook_package", choices=sorted(TASKS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=512)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from oracle import vita_oracle as O   # weights generator + cpu_baseline leg only
+    from vita_amd import ops, _lib
+    _lib.load()
+
+    obs_dim, A = TASKS[args.task]
+    B, K = args.batch, args.ode_steps
+    sd = O.make_state_dict(obs_dim, A, seed=0)
+    fw, dw = ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev)
+    ow, ob = sd["obs_encoder.weight"].to(dev), sd["obs_encoder.bias"].to(dev)
+    g = torch.Generator().manual_seed(1 + rank)
+    obs = torch.randn(B, obs_dim, generator=g).to(dev)
+    out = torch.empty(B, dw.OUT, device=dev)
+
+    def step():
+        ops.generate_actions(ow, ob, fw, dw, obs, K, out=out)
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed * 1e3 / args.steps
+    chunks_per_s = world * B * args.steps / elapsed
+    fpc = flops_per_chunk(obs_dim, fw.D, fw.H, fw.FF, fw.L, K, dw.HD, dw.w.NL, dw.OUT)
+
+    # latent-only sampler (B,D)->(B,D): "the fused ODE sampler" of the north star
+    x0 = torch.randn(B, fw.D, generator=g).to(dev)
+    for _ in range(2):
+        ops.ode_sample(fw, x0, K)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    n_lat = max(3, args.steps // 2)
+    for _ in range(n_lat):
+        ops.ode_sample(fw, x0, K)
+    torch.cuda.synchronize(dev)
+    lat_ms = (time.perf_counter() - t0) * 1e3 / n_lat
+    f_step = 2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D
+    lat_tflops = B * K * f_step / (lat_ms * 1e-3) / 1e12
+
+    # ---- per-kernel roofline: HIP events around the dominant GEMM classes, on the launch stream
+    def time_linear(M, N, Kd, reps=20, **kw):
+        x = torch.randn(M, Kd, device=dev)
+        w = torch.randn(N, Kd, device=dev) / Kd ** 0.5
+        bias = torch.randn(N, device=dev)
+        y = torch.empty(M, N, device=dev)
+        extra = {}
+        if kw.get("ln"):
+            extra = dict(pro=_lib.PRO_LN_MOD, ln_eps=1e-6, pro_mul=torch.randn(Kd, device=dev) * 0.1,
+                         pro_add=torch.randn(Kd, device=dev) * 0.1)
+        if kw.get("gated"):
+            extra.update(gate=torch.randn(N, device=dev), resid=y)
+        for _ in range(3):
+            ops.linear(x, w, bias, kw.get("act", 0), out=y, **extra)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            ops.linear(x, w, bias, kw.get("act", 0), out=y, **extra)
+        e1.record()
+        e1.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+    kernels = {}
+    if rank == 0:
+        for name, (M, N, Kd, kw) in {
+            "fc1 gemm_f32<128,128,32,LN> 4096x2048x512 ln_mod+gelu_tanh": (B, fw.FF, fw.H, dict(ln=True, act=_lib.ACT_GELU_TANH)),
+            "fc2 gemm_f32<64,128,32> 4096x512x2048 gate+resid": (B, fw.H, fw.FF, dict(gated=True)),
+            "in_proj gemm_f32<64,128,32> 4096x512x512": (B, fw.H, fw.D, dict()),
+        }.items():
+            dt = time_linear(M, N, Kd, **kw)
+            fl = 2.0 * M * N * Kd
+            kernels[name] = {"avg_us": round(dt * 1e6, 2), "tflops": round(fl / dt / 1e12, 2),
+                             "frac_of_f32_mfma_peak": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+    dom = "fc1 gemm_f32<128,128,32,LN> 4096x2048x512 ln_mod+gelu_tanh"
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("fc1_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        # the oracle (CPU restatement of the reference, torch CPU fp32) on a bounded row sample
+        nthreads = min(16, os.cpu_count() or 1)
+        torch.set_num_threads(nthreads)
+        rows = args.cpu_rows
+        cobs = obs[:rows].cpu()
+        with torch.no_grad():
+            O.generate_actions(sd, cobs, K, 16, A)
+            t0 = time.perf_counter()
+            n = 0
+            while True:
+                O.generate_actions(sd, cobs, K, 16, A)
+                n += 1
+                if time.perf_counter() - t0 > 12.0 or n >= 50:
+                    break
+            cdt = (time.perf_counter() - t0) / n
+        cpu = {"value": round(rows / cdt, 1), "unit": "action-chunks/s", "cores": nthreads, "kind": "port",
+               "sample": f"{n} passes of {rows} rows (same weights/inputs, K={K}), oracle/vita_oracle.generate_actions, torch {torch.__version__} CPU fp32"}
+
+    if rank == 0:
+        line = {
+            "metric": "ODE action-chunks/sec (bs 4096)",
+            "value": round(chunks_per_s, 1),
+            "unit": "action-chunks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.task} generate_actions: obs features (B,{obs_dim}) -> actions (B,16,{A})",
+                       "batch_per_gpu": B, "global_batch": B * world, "ode_steps": K,
+                       "latent_dim": fw.D, "hidden_dim": fw.H, "layers": fw.L, "mlp_ratio": fw.FF // fw.H,
+                       "parallelism": f"batch-sharded x{world}, no collective"},
+            "flops_per_chunk": fpc,
+            "whole_path_tflops": round(chunks_per_s * fpc / 1e12 / world, 2),
+            "whole_path_frac_of_f32_mfma_peak": round(chunks_per_s * fpc / 1e12 / world / PEAK_F32_MFMA_TFLOPS, 4),
+            "latent_only": {"ms_per_solve": round(lat_ms, 4), "chunks_per_s": round(B / (lat_ms * 1e-3), 1),
+                            "tflops": round(lat_tflops, 2),
+                            "frac_of_f32_mfma_peak": round(lat_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
+            "roofline": {"bound": "mfma", "kernel": dom,
+                         "achieved": kernels[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                         "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic,
+                         "flops_per_launch": 2.0 * B * fw.FF * fw.H},
+            "kernels": kernels,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

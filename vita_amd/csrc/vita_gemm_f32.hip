@@ -265,6 +265,7 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
+    if (a.M == 0 && a.N > 0 && a.K > 0) return VITA_OK;  // empty batch: nothing to do (pointers may be null)
     VITA_REQUIRE(a.X && a.W && a.Y, "vita_linear_f32: X, W and Y must be non-null");
     VITA_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "vita_linear_f32: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     VITA_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N,
@@ -281,8 +282,6 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "vita_linear_f32: ld_resid must be >= N");
     VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W,
                  "vita_linear_f32: Y must not alias X or W");
-    if (a.M == 0) return VITA_OK;
-
     GemmParams p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias;
     p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K;
