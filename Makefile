@@ -3,7 +3,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := vita_amd/csrc
-SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_elementwise.hip
+SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_gemm_f32_dma.hip $(CSRC)/vita_elementwise.hip
 HDRS  := $(CSRC)/vita_common.h include/vita_hip.h
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vita_amd/libvita_hip.so
@@ -20,4 +20,8 @@ $(LIB): $(OBJS)
 clean:
 	rm -f $(OBJS) $(LIB)
 
+
+
+tools/bench_gemm: tools/bench_gemm.cpp $(LIB) include/vita_hip.h
+	$(HIPCC) --offload-arch=$(ARCH) -O2 -std=c++17 tools/bench_gemm.cpp -o $@ -Lvita_amd -lvita_hip -Wl,-rpath,'$$ORIGIN/../vita_amd'
 .PHONY: all clean

@@ -133,18 +133,19 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
+    FC1 = "fc1 gemm_f32_dma<128,128,32,4> 4096x2048x512 bias+gelu_tanh"
     kernels = {}
     if rank == 0:
         for name, (M, N, Kd, kw) in {
-            "fc1 gemm_f32<128,128,32,LN> 4096x2048x512 ln_mod+gelu_tanh": (B, fw.FF, fw.H, dict(ln=True, act=_lib.ACT_GELU_TANH)),
-            "fc2 gemm_f32<64,128,32> 4096x512x2048 gate+resid": (B, fw.H, fw.FF, dict(gated=True)),
-            "in_proj gemm_f32<64,128,32> 4096x512x512": (B, fw.H, fw.D, dict()),
+            FC1: (B, fw.FF, fw.H, dict(act=_lib.ACT_GELU_TANH)),
+            "fc2 gemm_f32_dma<64,128,32,4> 4096x512x2048 bias+gate+resid": (B, fw.H, fw.FF, dict(gated=True)),
+            "in_proj gemm_f32_dma<64,128,32,4> 4096x512x512 bias": (B, fw.H, fw.D, dict()),
         }.items():
             dt = time_linear(M, N, Kd, **kw)
             fl = 2.0 * M * N * Kd
             kernels[name] = {"avg_us": round(dt * 1e6, 2), "tflops": round(fl / dt / 1e12, 2),
                              "frac_of_f32_mfma_peak": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-    dom = "fc1 gemm_f32<128,128,32,LN> 4096x2048x512 ln_mod+gelu_tanh"
+    dom = FC1
 
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")

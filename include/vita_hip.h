@@ -188,6 +188,13 @@ int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, c
 int vita_normalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, vita_stream_t stream);
 int vita_unnormalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, vita_stream_t stream);
 
+/* LayerNorm over the last dim H fused with its following elementwise op, one pass over x:
+ *   mode VITA_PRO_LN_MOD   : y = LN(x; no affine, eps) * (1 + mul) + add   — FlowNetLayer, simple_flow_net.py:44-45
+ *   mode VITA_PRO_LN_AFFINE: y = LN(x; eps) * mul + add                    — SimpleFlowNet.norm, simple_flow_net.py:81,106
+ * mul/add are (H) vectors (ld = 0) or (M,H) matrices (per-row t).  H <= 2048. */
+int vita_layernorm_modulate_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t H, float eps, int32_t mode,
+                                const float* mul, int64_t ld_mul, const float* add, int64_t ld_add, vita_stream_t stream);
+
 /* Sinusoidal time embedding, pos_embed.py:11-18: t (B) -> (B, dim) = cat(sin(t f), cos(t f)). */
 int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B, int32_t dim, vita_stream_t stream);
 

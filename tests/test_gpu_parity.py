@@ -324,5 +324,19 @@ def test_normalize_golden(ops, dev, misc):
     close(ops.unnormalize(d("norm_act"), d("act_mean"), d("act_std")), misc[n + "unnorm_act"], 1e-6)
 
 
+@pytest.mark.parametrize("M,H", [(1, 4), (5, 32), (37, 100), (300, 512), (64, 2048), (9, 33)])
+@pytest.mark.parametrize("per_row", [False, True])
+def test_layernorm_modulate(ops, dev, M, H, per_row):
+    from vita_amd import _lib as L
+    g = torch.Generator().manual_seed(M + H)
+    x = torch.randn(M, H, generator=g) * 2 + 1
+    shp = (M, H) if per_row else (H,)
+    mul, add = torch.randn(*shp, generator=g) * 0.3, torch.randn(*shp, generator=g) * 0.3
+    xn = torch.nn.functional.layer_norm(x.double(), (H,), None, None, 1e-6)
+    close(ops.layernorm_modulate(x.to(dev), mul.to(dev), add.to(dev), 1e-6, L.PRO_LN_MOD), xn * (1 + mul.double()) + add.double(), 2e-6)
+    xn5 = torch.nn.functional.layer_norm(x.double(), (H,), None, None, 1e-5)
+    close(ops.layernorm_modulate(x.to(dev), mul.to(dev), add.to(dev), 1e-5, L.PRO_LN_AFFINE), xn5 * mul.double() + add.double(), 2e-6)
+
+
 def test_sinusoid_golden(ops, dev, misc):
     close(ops.sinusoidal_embed(misc["misc/sin_t"].to(dev), 256), misc["misc/sin_e"], 1e-6)

@@ -1,0 +1,48 @@
+// Standalone micro-benchmark of vita_linear_f32 through the C ABI (no Python), for rocprofv3
+// counter passes and quick A/B of kernel variants:  bench_gemm M N K ln act gated reps
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../include/vita_hip.h"
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+int main(int argc, char** argv) {
+    int M = argc > 1 ? atoi(argv[1]) : 4096, N = argc > 2 ? atoi(argv[2]) : 2048, K = argc > 3 ? atoi(argv[3]) : 512;
+    int ln = argc > 4 ? atoi(argv[4]) : 0, act = argc > 5 ? atoi(argv[5]) : 0, gated = argc > 6 ? atoi(argv[6]) : 0;
+    int reps = argc > 7 ? atoi(argv[7]) : 50;
+    int padx = argc > 8 ? atoi(argv[8]) : 0, padw = argc > 9 ? atoi(argv[9]) : 0;
+    const size_t ldx = K + padx, ldw = K + padw;
+    std::vector<float> hx((size_t)M * ldx), hw((size_t)N * ldw), hv(N > K ? N : K);
+    srand(1);
+    for (auto& v : hx) v = (rand() / (float)RAND_MAX) * 2 - 1;
+    for (auto& v : hw) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.05f;
+    for (auto& v : hv) v = ((rand() / (float)RAND_MAX) * 2 - 1) * 0.1f;
+    float *x, *w, *b, *y, *pm, *pa, *g;
+    CK(hipMalloc(&x, hx.size() * 4)); CK(hipMalloc(&w, hw.size() * 4)); CK(hipMalloc(&b, N * 4));
+    CK(hipMalloc(&y, (size_t)M * N * 4)); CK(hipMalloc(&pm, K * 4)); CK(hipMalloc(&pa, K * 4)); CK(hipMalloc(&g, N * 4));
+    CK(hipMemcpy(x, hx.data(), hx.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(b, hv.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(pm, hv.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(pa, hv.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(g, hv.data(), N * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(y, 0, (size_t)M * N * 4));
+    vita_linear_args a = {};
+    a.X = x; a.ldx = ldx; a.W = w; a.ldw = ldw; a.bias = b; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act;
+    if (ln) { a.pro = VITA_PRO_LN_MOD; a.ln_eps = 1e-6f; a.pro_mul = pm; a.pro_add = pa; }
+    if (gated) { a.gate = g; a.resid = y; a.ld_resid = N; }
+    for (int i = 0; i < 5; ++i) if (vita_linear_f32(&a, 0) != 0) { printf("err: %s\n", vita_last_error()); return 1; }
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) vita_linear_f32(&a, 0);
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+    printf("padx=%d padw=%d ", padx, padw);
+    printf("M=%d N=%d K=%d ln=%d act=%d gated=%d : %.2f us  %.2f TFLOP/s  %.1f%% of 157.3\n", M, N, K, ln, act, gated, us, tf, tf / 157.3 * 100);
+    return 0;
+}

@@ -37,10 +37,11 @@ void set_error(const char* fmt, ...);
 __device__ __forceinline__ float act_gelu_tanh(float x) {
     const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
     const float kKappa = 0.044715f;
-    float x3 = x * x * x;
-    float inner = kBeta * (x + kKappa * x3);
-    float e = __expf(-2.0f * inner);
-    return x / (1.0f + e);
+    const float x3 = x * x * x;
+    const float inner = kBeta * (x + kKappa * x3);
+    // exp(-2*inner) = exp2(-2*log2(e)*inner): v_exp_f32 and v_rcp_f32 are 1-ulp instructions
+    const float e = __builtin_amdgcn_exp2f(inner * -2.8853900817779268f);
+    return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float act_gelu_erf(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
@@ -60,6 +61,16 @@ __device__ __forceinline__ float apply_act(float x, int act) {
         case VITA_ACT_MISH: return act_mish(x);
         default: return x;
     }
+}
+
+template <int ACT>
+__device__ __forceinline__ float apply_act_t(float x) {
+    if constexpr (ACT == VITA_ACT_RELU) return x > 0.0f ? x : 0.0f;
+    else if constexpr (ACT == VITA_ACT_GELU_ERF) return act_gelu_erf(x);
+    else if constexpr (ACT == VITA_ACT_GELU_TANH) return act_gelu_tanh(x);
+    else if constexpr (ACT == VITA_ACT_SILU) return act_silu(x);
+    else if constexpr (ACT == VITA_ACT_MISH) return act_mish(x);
+    else return x;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -145,6 +145,86 @@ __global__ __launch_bounds__(EW_THREADS) void norm_kernel(const float* __restric
     }
 }
 
+// ---- LayerNorm (+ modulation / affine), one wave per row --------------------------------------
+// y = ((x - mean) * rstd) * m + a,  m = mul (+1 when MOD), two-pass statistics held in registers.
+// The row (H floats) is read once: lane l holds float4 chunks l, l+64, ... (H <= 64*4*LN_MAXC).
+constexpr int LN_MAXC = 8;
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                     int M, int H, float eps, int mod, const float* __restrict__ mul, int64_t ld_mul,
+                                                     const float* __restrict__ add, int64_t ld_add, int vec) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * ldx;
+    float* yr = y + (int64_t)row * ldy;
+    const float* mr = mul + (int64_t)row * ld_mul;
+    const float* ar = add + (int64_t)row * ld_add;
+    f32x4 v[LN_MAXC];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int k = (c * 64 + lane) * 4;
+        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (k < H) {
+            if (vec) v[c] = *reinterpret_cast<const f32x4*>(xr + k);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k + j < H) v[c][j] = xr[k + j];
+            }
+        }
+        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
+    }
+    s = wave_sum(s);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int k = (c * 64 + lane) * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = (k + j < H) ? v[c][j] - mu : 0.f;
+            q = fmaf(d, d, q);
+        }
+    }
+    q = wave_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+#pragma unroll
+    for (int c = 0; c < LN_MAXC; ++c) {
+        const int k = (c * 64 + lane) * 4;
+        if (k < H) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (k + j < H) {
+                    const float n = (v[c][j] - mu) * rstd;
+                    const float m = mod ? (mr[k + j] + 1.0f) : mr[k + j];
+                    o[j] = n * m + ar[k + j];
+                }
+            }
+            if (vec) *reinterpret_cast<f32x4*>(yr + k) = o;
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (k + j < H) yr[k + j] = o[j];
+            }
+        }
+    }
+}
+
+int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
+                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s) {
+    VITA_REQUIRE(x && y && mul && add, "vita_layernorm_modulate_f32: null pointer");
+    VITA_REQUIRE(M >= 0 && H > 0 && H <= 64 * 4 * LN_MAXC, "vita_layernorm_modulate_f32: H=%d outside (0, %d]", H, 64 * 4 * LN_MAXC);
+    VITA_REQUIRE(ldx >= H && ldy >= H && (ld_mul == 0 || ld_mul >= H) && (ld_add == 0 || ld_add >= H),
+                 "vita_layernorm_modulate_f32: bad leading dimension");
+    VITA_REQUIRE(mode == VITA_PRO_LN_MOD || mode == VITA_PRO_LN_AFFINE, "vita_layernorm_modulate_f32: mode must be LN_MOD or LN_AFFINE");
+    if (M == 0) return VITA_OK;
+    const int vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y);
+    hipLaunchKernelGGL(ln_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps, mode == VITA_PRO_LN_MOD ? 1 : 0,
+                       mul, ld_mul, add, ld_add, vec);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
 // ---- sinusoidal embedding --------------------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int64_t ldo,
                                                             int B, int dim) {
@@ -230,6 +310,11 @@ int vita_unnormalize_f32(const float* x, const float* mean, const float* sd, flo
                        rows * C, C);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
+}
+
+int vita_layernorm_modulate_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t H, float eps, int32_t mode,
+                                const float* mul, int64_t ld_mul, const float* add, int64_t ld_add, vita_stream_t stream) {
+    return launch_ln_mod(x, ldx, y, ldy, M, H, eps, mode, mul, ld_mul, add, ld_add, (hipStream_t)stream);
 }
 
 int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B, int32_t dim, vita_stream_t stream) {

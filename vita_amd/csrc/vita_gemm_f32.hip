@@ -7,15 +7,17 @@
 //
 // Tiling (one workgroup = 512 threads = 8 waves, 2 per SIMD):
 //   block tile BM x BN, waves laid out 2 (M) x 4 (N), wave tile (BM/2) x (BN/4) made of
-//   32x32 MFMA accumulators; K is walked in BK-deep tiles, double-buffered in LDS:
-//     global -> registers (issued before the MFMAs of the current tile)
-//            -> [LayerNorm/modulation prologue on the A rows] -> LDS (after the MFMAs)
-//   one barrier per K tile.  LDS rows are padded to BK+4 floats: the ds_read_b128 fragment
+//   32x32 MFMA accumulators; K is walked in BK-deep tiles through a ring of 3 LDS buffers:
+//     global -> registers (two tiles ahead) -> [LayerNorm/modulation prologue on the A rows]
+//            -> LDS (one tile ahead) -> fragment registers (one 8-deep chunk ahead) -> MFMA
+//   one barrier per K tile, and no LDS or global wait on the MFMA stream's critical path.  LDS rows are padded to BK+4 floats: the ds_read_b128 fragment
 //   reads (32 rows x 16 B per half-wave) and the ds_write_b128 staging writes are then
 //   bank-conflict-free (row stride = 4*odd dwords).
 //   A ds_read_b128 gives a lane 4 consecutive k of its row; lanes 0-31 take k = 8c..8c+3,
 //   lanes 32-63 k = 8c+4..8c+7, so register j of the A and B fragments pair k = 8c+j with
 //   8c+4+j in one 32x32x2 MFMA: 4 MFMAs per pair of 16-byte LDS reads.
+#include <type_traits>
+
 #include "vita_common.h"
 
 namespace vita {
@@ -39,21 +41,30 @@ struct GemmParams {
 
 constexpr int NT = 512;
 
-__device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int k, int K, bool row_ok, bool vec) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (row_ok) {
-        if (vec) {
-            if (k < K) v = *reinterpret_cast<const f32x4*>(row + k);
-        } else {
+// A page of zeros: loads whose k lies beyond K are redirected here by an ADDRESS select, so the
+// loaded registers are not touched until they are written to LDS (a data select right after the
+// load would make the compiler wait for the load at issue time and serialise the pipeline).
+__device__ __attribute__((aligned(16))) float g_zero_page[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Guarded load of 4 consecutive k of one row.  Rows beyond M / N are clamped by the caller to
+// the last valid row; their products are discarded at the store.
+template <bool VEC>
+__device__ __forceinline__ f32x4 load4(const float* __restrict__ row, int k, int K) {
+    f32x4 v;
+    if constexpr (VEC) {  // K % 4 == 0, 16-byte aligned rows
+        const float* src = (k < K) ? row + k : g_zero_page;
+        v = *reinterpret_cast<const f32x4*>(src);
+    } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k + j < K) v[j] = row[k + j];
+        for (int j = 0; j < 4; ++j) {
+            const float* src = (k + j) < K ? row + k + j : g_zero_page;
+            v[j] = *src;
         }
     }
     return v;
 }
 
-template <int BM, int BN, int BK, bool LN>
+template <int BM, int BN, int BK, bool LN, bool VEC>
 __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     constexpr int S = BK + 4;             // padded LDS row stride (floats)
     constexpr int C4 = BK / 4;            // float4 slots per tile row
@@ -64,8 +75,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     static_assert(A_SLOTS >= 1 && B_SLOTS >= 1 && MI >= 1 && NI >= 1, "tile too small");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                      // [2][BM][S]
-    float* Bs = smem + 2 * BM * S;         // [2][BN][S]
+    float* As = smem;                      // [3][BM][S]
+    float* Bs = smem + 3 * BM * S;         // [3][BN][S]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -88,48 +99,58 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
     // per-thread staging slots
     int a_row[A_SLOTS], a_c[A_SLOTS];
     const float* a_ptr[A_SLOTS];
-    bool a_ok[A_SLOTS];
+    int a_grow[A_SLOTS];
 #pragma unroll
     for (int i = 0; i < A_SLOTS; ++i) {
         const int s = tid + i * NT;
         a_row[i] = s / C4;
         a_c[i] = (s % C4) * 4;
-        a_ok[i] = (m0 + a_row[i]) < p.M;
-        a_ptr[i] = p.X + (int64_t)(m0 + a_row[i]) * p.ldx;
+        a_grow[i] = min(m0 + a_row[i], p.M - 1);
+        a_ptr[i] = p.X + (int64_t)a_grow[i] * p.ldx;
     }
     int b_row[B_SLOTS], b_c[B_SLOTS];
     const float* b_ptr[B_SLOTS];
-    bool b_ok[B_SLOTS];
 #pragma unroll
     for (int i = 0; i < B_SLOTS; ++i) {
         const int s = tid + i * NT;
         b_row[i] = s / C4;
         b_c[i] = (s % C4) * 4;
-        b_ok[i] = (n0 + b_row[i]) < p.N;
-        b_ptr[i] = p.W + (int64_t)(n0 + b_row[i]) * p.ldw;
+        b_ptr[i] = p.W + (int64_t)min(n0 + b_row[i], p.N - 1) * p.ldw;
     }
 
     // ---- LayerNorm statistics of this block's rows (two-pass, over the whole K extent) ----
+    // Loads are issued SB at a time before any is consumed so they overlap; for K <= SB*BK the
+    // row stays in registers between the mean pass and the variance pass.
     float mean[A_SLOTS], rstd[A_SLOTS];
     if constexpr (LN) {
+        constexpr int SB = 16;
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
+            f32x4 v[SB];
             float s = 0.f;
-            for (int kt = 0; kt < nk; ++kt) {
-                f32x4 v = load4(a_ptr[i], kt * BK + a_c[i], K, a_ok[i], p.vec_x);
-                s += (v[0] + v[1]) + (v[2] + v[3]);
+            for (int kb = 0; kb < nk; kb += SB) {
+#pragma unroll
+                for (int u = 0; u < SB; ++u) v[u] = load4<VEC>(a_ptr[i], (kb + u) * BK + a_c[i], K);
+#pragma unroll
+                for (int u = 0; u < SB; ++u) s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
             }
 #pragma unroll
             for (int o = C4 / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
             const float mu = s / (float)K;
             float q = 0.f;
-            for (int kt = 0; kt < nk; ++kt) {
-                const int k = kt * BK + a_c[i];
-                f32x4 v = load4(a_ptr[i], k, K, a_ok[i], p.vec_x);
+            for (int kb = 0; kb < nk; kb += SB) {
+                if (nk > SB) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float d = (k + j < K) ? v[j] - mu : 0.f;
-                    q = fmaf(d, d, q);
+                    for (int u = 0; u < SB; ++u) v[u] = load4<VEC>(a_ptr[i], (kb + u) * BK + a_c[i], K);
+                }
+#pragma unroll
+                for (int u = 0; u < SB; ++u) {
+                    const int k = (kb + u) * BK + a_c[i];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = (k + j < K) ? v[u][j] - mu : 0.f;
+                        q = fmaf(d, d, q);
+                    }
                 }
             }
 #pragma unroll
@@ -146,16 +167,16 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
         for (int i = 0; i < A_SLOTS; ++i) {
             const int k = kt * BK + a_c[i];
-            a_reg[i] = load4(a_ptr[i], k, K, a_ok[i], p.vec_x);
+            a_reg[i] = load4<VEC>(a_ptr[i], k, K);
             if constexpr (LN) {
-                const int64_t r = m0 + a_row[i];
-                pm_reg[i] = load4(p.pro_mul + r * p.ld_pro_mul, k, K, a_ok[i], p.vec_p);
-                pa_reg[i] = load4(p.pro_add + r * p.ld_pro_add, k, K, a_ok[i], p.vec_p);
+                const int64_t r = a_grow[i];
+                pm_reg[i] = load4<VEC>(p.pro_mul + r * p.ld_pro_mul, k, K);
+                pa_reg[i] = load4<VEC>(p.pro_add + r * p.ld_pro_add, k, K);
             }
         }
 #pragma unroll
         for (int i = 0; i < B_SLOTS; ++i)
-            b_reg[i] = load4(b_ptr[i], kt * BK + b_c[i], K, b_ok[i], p.vec_w);
+            b_reg[i] = load4<VEC>(b_ptr[i], kt * BK + b_c[i], K);
     };
     auto write_lds = [&](int buf) {
 #pragma unroll
@@ -185,65 +206,108 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    issue_loads(0);
-    write_lds(0);
-    __syncthreads();
-
+    // ---- main loop: 3 LDS buffers, fragment reads software-pipelined one chunk ahead -------
+    // iteration kt:  MFMAs read tile kt from buf[kt%3]; tile kt+1 is already complete in
+    // buf[(kt+1)%3] (written during kt-1, barrier passed), so the last chunk prefetches its
+    // first fragments across the barrier; the registers holding tile kt+2 (loaded during kt-1)
+    // are written to buf[(kt+2)%3] and re-used for the global loads of tile kt+3.
+    constexpr int NCH = BK / 8;
+    static_assert(NCH % 2 == 0, "fragment double-buffer parity");
     const int frag_row = lane & 31;
     const int frag_k = (lane >> 5) * 4;
+    const float* Afr = &As[(wm * TM + frag_row) * S + frag_k];
+    const float* Bfr = &Bs[(wn * TN + frag_row) * S + frag_k];
+    f32x4 af[2][MI], bf[2][NI];
+    auto read_frags = [&](int buf, int kc, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(Afr + (buf * BM + i * 32) * S + kc * 8);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bfr + (buf * BN + j * 32) * S + kc * 8);
+    };
+
+    issue_loads(0);
+    write_lds(0);
+    if (nk > 1) {
+        issue_loads(1);
+        write_lds(1);
+    }
+    if (nk > 2) issue_loads(2);
+    __syncthreads();
+    read_frags(0, 0, af[0], bf[0]);
+
+    int buf = 0;
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_loads(kt + 1);
-        const float* Ab = &As[(buf * BM + wm * TM + frag_row) * S + frag_k];
-        const float* Bb = &Bs[(buf * BN + wn * TN + frag_row) * S + frag_k];
+        const int buf1 = buf == 2 ? 0 : buf + 1;
+        const int buf2 = buf1 == 2 ? 0 : buf1 + 1;
 #pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {
-            f32x4 af[MI], bf[NI];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * S + kc * 8);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * S + kc * 8);
+        for (int kc = 0; kc < NCH; ++kc) {
+            // The body is branch-free on purpose (a conditional prefetch gets sunk below the MFMAs
+            // by the compiler and exposes the LDS latency after every barrier): past the last
+            // tile the prefetch reads a stale-but-valid buffer, the staging write lands in a
+            // buffer nobody reads again, and load4 redirects k >= K to the zero page.
+            // LDS ops retire in order, so the staging writes go after the first MFMA group:
+            // nothing but already-landed fragments gates the first MFMA after the barrier.
+#if !defined(VITA_LAB) || (VITA_LAB != 2 && VITA_LAB != 4)
+            if (kc == 1) write_lds(buf2);
+#endif
+#if !defined(VITA_LAB) || (VITA_LAB != 3 && VITA_LAB != 4)
+            if (kc == 2) issue_loads(kt + 3);
+#endif
+            if (kc + 1 < NCH) read_frags(buf, kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
+            else read_frags(buf1, 0, af[0], bf[0]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][i][e], bf[kc & 1][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (kt + 1 < nk) write_lds(buf ^ 1);
+#if !defined(VITA_LAB) || VITA_LAB != 1
         __syncthreads();
+#endif
+        buf = buf1;
     }
 
     // ---- epilogue: bias, activation, gate, residual --------------------------------------
-    const int act = p.act;
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = n0 + wn * TN + j * 32 + (lane & 31);
-        const bool col_ok = col < p.N;
-        const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-        float gcol = p.use_gate_scalar ? p.gate_scalar : 1.0f;
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
         const bool gate_vec = (p.gate != nullptr) && (p.ld_gate == 0);
         const bool gate_mat = (p.gate != nullptr) && (p.ld_gate != 0);
-        if (gate_vec && col_ok) gcol = p.gate[col];
         const bool has_gate = p.use_gate_scalar || (p.gate != nullptr);
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * TN + j * 32 + (lane & 31);
+            const bool col_ok = col < p.N;
+            const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+            float gcol = p.use_gate_scalar ? p.gate_scalar : 1.0f;
+            if (gate_vec && col_ok) gcol = p.gate[col];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < p.M && col_ok) {
-                    float v = acc[i][j][r] + bias;
-                    v = apply_act(v, act);
-                    if (has_gate) {
-                        const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
-                        v = v * g;
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < p.M && col_ok) {
+                        float v = apply_act_t<ACT>(acc[i][j][r] + bias);
+                        if (has_gate) {
+                            const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
+                            v = v * g;
+                        }
+                        if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
+                        p.Y[(int64_t)row * p.ldy + col] = v;
                     }
-                    if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
-                    p.Y[(int64_t)row * p.ldy + col] = v;
                 }
             }
         }
+    };
+    switch (p.act) {
+        case VITA_ACT_RELU: epilogue(std::integral_constant<int, VITA_ACT_RELU>{}); break;
+        case VITA_ACT_GELU_ERF: epilogue(std::integral_constant<int, VITA_ACT_GELU_ERF>{}); break;
+        case VITA_ACT_GELU_TANH: epilogue(std::integral_constant<int, VITA_ACT_GELU_TANH>{}); break;
+        case VITA_ACT_SILU: epilogue(std::integral_constant<int, VITA_ACT_SILU>{}); break;
+        case VITA_ACT_MISH: epilogue(std::integral_constant<int, VITA_ACT_MISH>{}); break;
+        default: epilogue(std::integral_constant<int, VITA_ACT_NONE>{}); break;
     }
 }
 
@@ -252,17 +316,24 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
     GemmParams p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    const size_t lds = (size_t)3 * (BM + BN) * (BK + 4) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(NT);
-    if (p.pro != VITA_PRO_NONE)
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true>), grid, block, lds, stream, p);
-    else
-        hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false>), grid, block, lds, stream, p);
+    const bool vec = p.vec_x && p.vec_w && (p.pro == VITA_PRO_NONE || p.vec_p);
+    if (p.pro != VITA_PRO_NONE) {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, true, false>), grid, block, lds, stream, p);
+    } else {
+        if (vec) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, BK, false, false>), grid, block, lds, stream, p);
+    }
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream);
+bool gemm_f32_dma_eligible(const vita_linear_args& a);
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     if (a.M == 0 && a.N > 0 && a.K > 0) return VITA_OK;  // empty batch: nothing to do (pointers may be null)
@@ -282,6 +353,10 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "vita_linear_f32: ld_resid must be >= N");
     VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W,
                  "vita_linear_f32: Y must not alias X or W");
+#if !defined(VITA_LAB) || VITA_LAB != 7
+    if (gemm_f32_dma_eligible(a)) return gemm_f32_dma(a, stream);
+#endif
+
     GemmParams p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias;
     p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K;

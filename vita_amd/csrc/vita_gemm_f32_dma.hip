@@ -1,0 +1,405 @@
+// fp32 MFMA GEMM, LDS-DMA variant — the fast path of vita_linear_f32 for 16-byte-aligned
+// operands (every GEMM of the sampler except obs_encoder's K=533).
+//
+//   Y[M,N] = resid + gate * act( pro(X)[M,K] · W[N,K]^T + bias )
+//
+// Why a second kernel: staging fp32 tiles through VGPRs costs a ds_write_b128 per 1 KiB
+// (13 LDS cycles each) on the same LDS port the fragment reads use; measured, those writes
+// and their vmcnt waits took ~20 % of the k-loop.  Here both operand tiles go global -> LDS
+// directly (global_load_lds_dwordx4, no VGPRs, no ds_write), NS stages deep:
+//
+//   stage image : [rows][BK floats], UNPADDED (an LDS-DMA wave-instruction writes 1 KiB
+//                 linearly: 8 rows x 128 B at BK=32, 4 rows x 256 B at BK=64), with the 16-byte
+//                 chunks of row r XOR-swizzled (chunk c stored at position c ^ f(r)) so the
+//                 ds_read_b128 fragment reads (32 rows x 16 B per half-wave) hit 16 distinct
+//                 16-byte bank slots.  The swizzle is applied on the per-lane GLOBAL source
+//                 address (the LDS side of a DMA is lane-linear) and again on the read.
+//   k-loop      : per tile ONE counted s_waitcnt vmcnt + ONE raw s_barrier; the DMAs of the
+//                 next NS-2 tiles stay in flight across it; fragment reads run one 8-deep chunk
+//                 ahead of the MFMAs, including across the barrier (tile kt+1 is complete one
+//                 iteration early).
+//   LayerNorm   : cannot be applied while staging (the data never passes through registers),
+//                 so it is applied to the A fragments after the LDS read: (a-mean)*rstd from
+//                 per-lane row statistics, then *mul[k] + add[k] from LDS tables — VALU work
+//                 that hides under the 64-cycle fp32 MFMAs.
+#include <type_traits>
+
+#include "vita_common.h"
+
+namespace vita {
+
+struct GemmParams;  // defined in vita_gemm_f32.hip; the layout is repeated here
+
+struct GemmParamsDma {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;
+    float* Y; int64_t ldy;
+    int M, N, K;
+    int act, pro;
+    float ln_eps;
+    const float* pro_mul;
+    const float* pro_add;
+    const float* gate; int64_t ld_gate;
+    int use_gate_scalar; float gate_scalar;
+    const float* resid; int64_t ld_resid;
+    int tiles_m, tiles_n;
+};
+
+constexpr int DNT = 512;
+
+__device__ __attribute__((aligned(16))) float g_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// chunk swizzle: BK=32 -> 8 chunks/row, rows alternate halves of the 256-B bank row, f = (r>>1)&7
+//                BK=64 -> 16 chunks/row, one row per bank row,                        f = r&15
+template <int BK>
+__device__ __forceinline__ int swz(int r) {
+    if constexpr (BK == 32) return (r >> 1) & 7;
+    else return r & 15;
+}
+
+template <int BM, int BN, int BK, int NS, bool LN>
+__global__ __launch_bounds__(DNT) void gemm_f32_dma_kernel(GemmParamsDma p) {
+    constexpr int CH = BK / 4;                 // 16-byte chunks per tile row
+    constexpr int RPI = 64 / CH;               // rows covered by one DMA wave-instruction
+    constexpr int A_DMA = BM / RPI / 8;        // DMA instructions per wave per tile (A)
+    constexpr int B_DMA = BN / RPI / 8;
+    constexpr int DPT = A_DMA + B_DMA;
+    constexpr int TM = BM / 2, TN = BN / 4;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int NCH = BK / 8;
+    constexpr int STAGE = (BM + BN) * BK;      // floats per stage
+    static_assert(A_DMA >= 1 && B_DMA >= 1 && MI >= 1 && NI >= 1 && NCH % 2 == 0 && NS >= 3, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    // [NS][ A: BM x BK | B: BN x BK ]  then (LN only) mul[K], add[K], stats[BM][2]
+    float* lnm = smem + NS * STAGE;
+    float* lna = lnm + (LN ? p.K : 0);
+    float* stat = lna + (LN ? p.K : 0);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int K = p.K;
+    const int nk = (K + BK - 1) / BK;
+
+    // ---- per-lane DMA sources: lane l of instruction j writes row (j*8+wave)*RPI + l/CH,
+    //      chunk position l%CH, so it must fetch chunk (l%CH) ^ swz(row) of that row
+    const float* a_src[A_DMA];
+    int a_k[A_DMA];
+#pragma unroll
+    for (int j = 0; j < A_DMA; ++j) {
+        const int r = (j * 8 + wave) * RPI + lane / CH;
+        a_k[j] = ((lane % CH) ^ swz<BK>(r)) * 4;
+        a_src[j] = p.X + (int64_t)min(m0 + r, p.M - 1) * p.ldx + a_k[j];
+    }
+    const float* b_src[B_DMA];
+    int b_k[B_DMA];
+#pragma unroll
+    for (int j = 0; j < B_DMA; ++j) {
+        const int r = (j * 8 + wave) * RPI + lane / CH;
+        b_k[j] = ((lane % CH) ^ swz<BK>(r)) * 4;
+        b_src[j] = p.W + (int64_t)min(n0 + r, p.N - 1) * p.ldw + b_k[j];
+    }
+    auto issue_tile = [&](int kt, int stage) {
+        float* sa = smem + stage * STAGE;
+        float* sb = sa + BM * BK;
+        const int kb = kt * BK;
+#pragma unroll
+        for (int j = 0; j < A_DMA; ++j) {
+            const float* g = (kb + a_k[j] < K) ? a_src[j] + kb : g_zero_chunk;
+            dma16(g, sa + (j * 8 + wave) * RPI * BK);
+        }
+#pragma unroll
+        for (int j = 0; j < B_DMA; ++j) {
+            const float* g = (kb + b_k[j] < K) ? b_src[j] + kb : g_zero_chunk;
+            dma16(g, sb + (j * 8 + wave) * RPI * BK);
+        }
+    };
+
+    // prologue DMAs first: they fly while the LayerNorm statistics are computed
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_tile(s, s);
+
+    // ---- LayerNorm: tables into LDS, row statistics (two-pass) ---------------------------
+    float mean[MI], rstd[MI];
+    if constexpr (LN) {
+        const bool mod = p.pro == VITA_PRO_LN_MOD;
+        for (int k = tid * 4; k < K; k += DNT * 4) {
+            f32x4 m = *reinterpret_cast<const f32x4*>(p.pro_mul + k);
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.pro_add + k);
+            if (mod) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) m[j] = m[j] + 1.0f;
+            }
+            *reinterpret_cast<f32x4*>(lnm + k) = m;
+            *reinterpret_cast<f32x4*>(lna + k) = a;
+        }
+        // wave w owns rows w*BM/8 ..; a row is read 64 lanes x 16 B at a time
+        constexpr int RW = BM / 8;
+        constexpr int RB = 8;  // rows in flight
+        const int nseg = (K + 255) / 256;
+        for (int rb = 0; rb < RW; rb += RB) {
+            float s[RB];
+            f32x4 v0[RB], v1[RB];  // first two segments stay in registers (K <= 512: single read)
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const float* row = p.X + (int64_t)min(m0 + wave * RW + rb + u, p.M - 1) * p.ldx;
+                const int k0 = lane * 4, k1 = 256 + lane * 4;
+                v0[u] = *reinterpret_cast<const f32x4*>(k0 < K ? row + k0 : g_zero_chunk);
+                v1[u] = *reinterpret_cast<const f32x4*>(k1 < K ? row + k1 : g_zero_chunk);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                s[u] = ((v0[u][0] + v0[u][1]) + (v0[u][2] + v0[u][3])) + ((v1[u][0] + v1[u][1]) + (v1[u][2] + v1[u][3]));
+                const float* row = p.X + (int64_t)min(m0 + wave * RW + rb + u, p.M - 1) * p.ldx;
+                for (int sg = 2; sg < nseg; ++sg) {
+                    const int k = sg * 256 + lane * 4;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(k < K ? row + k : g_zero_chunk);
+                    s[u] += (v[0] + v[1]) + (v[2] + v[3]);
+                }
+                s[u] = wave_sum(s[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const float mu = s[u] / (float)K;
+                float q = 0.f;
+                const int k0 = lane * 4, k1 = 256 + lane * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float d0 = (k0 + j < K) ? v0[u][j] - mu : 0.f;
+                    const float d1 = (k1 + j < K) ? v1[u][j] - mu : 0.f;
+                    q = fmaf(d0, d0, q);
+                    q = fmaf(d1, d1, q);
+                }
+                const float* row = p.X + (int64_t)min(m0 + wave * RW + rb + u, p.M - 1) * p.ldx;
+                for (int sg = 2; sg < nseg; ++sg) {
+                    const int k = sg * 256 + lane * 4;
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(k < K ? row + k : g_zero_chunk);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float d = (k + j < K) ? v[j] - mu : 0.f;
+                        q = fmaf(d, d, q);
+                    }
+                }
+                q = wave_sum(q);
+                if (lane == 0) {
+                    stat[(wave * RW + rb + u) * 2 + 0] = mu;
+                    stat[(wave * RW + rb + u) * 2 + 1] = 1.0f / sqrtf(q / (float)K + p.ln_eps);
+                }
+            }
+        }
+    }
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- fragment addressing ---------------------------------------------------------------
+    const int fr = lane & 31, fh = lane >> 5;
+    int a_off[MI], a_sw[MI], b_off[NI], b_sw[NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int r = wm * TM + i * 32 + fr;
+        a_off[i] = r * BK;
+        a_sw[i] = swz<BK>(r);
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int r = wn * TN + j * 32 + fr;
+        b_off[j] = BM * BK + r * BK;
+        b_sw[j] = swz<BK>(r);
+    }
+    f32x4 af[2][MI], bf[2][NI], lm[2], la[2];
+    auto read_frags = [&](int stage, int kt, int kc, f32x4 (&a)[MI], f32x4 (&b)[NI], f32x4& m, f32x4& ad) {
+        const float* st = smem + stage * STAGE;
+        const int c = kc * 2 + fh;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + ((c ^ a_sw[i]) << 2));
+#pragma unroll
+        for (int j = 0; j < NI; ++j) b[j] = *reinterpret_cast<const f32x4*>(st + b_off[j] + ((c ^ b_sw[j]) << 2));
+        if constexpr (LN) {
+            int k = kt * BK + c * 4;
+            k = k < K ? k : 0;  // beyond K the W chunk is zero: any finite value will do
+            m = *reinterpret_cast<const f32x4*>(lnm + k);
+            ad = *reinterpret_cast<const f32x4*>(lna + k);
+        }
+    };
+    auto ln_apply = [&](f32x4 (&a)[MI], const f32x4& m, const f32x4& ad) {
+        if constexpr (LN) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float n = (a[i][e] - mean[i]) * rstd[i];
+                    a[i][e] = n * m[e] + ad[e];
+                }
+        }
+    };
+
+    // tile 0 (and 1) landed for everyone; LN tables / stats visible
+    wait_vmcnt<(NS - 3) * DPT>();
+    __syncthreads();
+    if constexpr (LN) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            mean[i] = stat[(wm * TM + i * 32 + fr) * 2 + 0];
+            rstd[i] = stat[(wm * TM + i * 32 + fr) * 2 + 1];
+        }
+    }
+    read_frags(0, 0, 0, af[0], bf[0], lm[0], la[0]);
+
+    int stage = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int stage1 = stage + 1 == NS ? 0 : stage + 1;
+        int stage_new = stage + NS - 1;
+        stage_new = stage_new >= NS ? stage_new - NS : stage_new;
+        if (kt > 0) {
+            // this wave's share of tile kt+1 has landed ...
+            wait_vmcnt<(NS - 3) * DPT>();
+            // ... and after the barrier everyone's has, and everyone is done reading tile kt-1
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+        issue_tile(kt + NS - 1, stage_new);   // refills the stage tile kt-1 lived in
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+            if (kc + 1 < NCH) read_frags(stage, kt, kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1], lm[(kc + 1) & 1], la[(kc + 1) & 1]);
+            else read_frags(stage1, kt + 1, 0, af[0], bf[0], lm[0], la[0]);
+            ln_apply(af[kc & 1], lm[kc & 1], la[kc & 1]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][i][e], bf[kc & 1][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the prefetched fragments must be in registers before the next barrier lets anyone
+        // overwrite... (they belong to tile kt+1, which is not overwritten until kt+2) — only
+        // the reads of tile kt must have retired, and they fed the MFMAs above.
+        stage = stage1;
+    }
+    wait_vmcnt<0>();  // drain the dummy tail DMAs before the wave exits / LDS is released
+
+    // ---- epilogue: bias, activation, gate, residual --------------------------------------
+    auto epilogue = [&](auto act_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        const bool gate_vec = (p.gate != nullptr) && (p.ld_gate == 0);
+        const bool gate_mat = (p.gate != nullptr) && (p.ld_gate != 0);
+        const bool has_gate = p.use_gate_scalar || (p.gate != nullptr);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int col = n0 + wn * TN + j * 32 + (lane & 31);
+            const bool col_ok = col < p.N;
+            const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+            float gcol = p.use_gate_scalar ? p.gate_scalar : 1.0f;
+            if (gate_vec && col_ok) gcol = p.gate[col];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < p.M && col_ok) {
+                        float v = apply_act_t<ACT>(acc[i][j][r] + bias);
+                        if (has_gate) {
+                            const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
+                            v = v * g;
+                        }
+                        if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
+                        p.Y[(int64_t)row * p.ldy + col] = v;
+                    }
+                }
+            }
+        }
+    };
+    switch (p.act) {
+        case VITA_ACT_RELU: epilogue(std::integral_constant<int, VITA_ACT_RELU>{}); break;
+        case VITA_ACT_GELU_ERF: epilogue(std::integral_constant<int, VITA_ACT_GELU_ERF>{}); break;
+        case VITA_ACT_GELU_TANH: epilogue(std::integral_constant<int, VITA_ACT_GELU_TANH>{}); break;
+        case VITA_ACT_SILU: epilogue(std::integral_constant<int, VITA_ACT_SILU>{}); break;
+        case VITA_ACT_MISH: epilogue(std::integral_constant<int, VITA_ACT_MISH>{}); break;
+        default: epilogue(std::integral_constant<int, VITA_ACT_NONE>{}); break;
+    }
+}
+
+template <int BM, int BN, int BK, int NS>
+static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
+    GemmParamsDma p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const bool ln = p.pro != VITA_PRO_NONE;
+    const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0)) * sizeof(float);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(DNT);
+    if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false>), grid, block, lds, stream, p);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+// Eligibility is decided by the caller (vita_gemm_f32.hip): 16-byte aligned X/W rows, K % 4 == 0,
+// LayerNorm vectors broadcast over rows (ld == 0) and K small enough for the LDS tables.
+int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
+    GemmParamsDma p{};
+    p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias;
+    p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K;
+    p.act = a.act; p.pro = a.pro; p.ln_eps = a.ln_eps;
+    p.pro_mul = a.pro_mul; p.pro_add = a.pro_add;
+    p.gate = a.gate; p.ld_gate = a.ld_gate;
+    p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
+    p.resid = a.resid; p.ld_resid = a.ld_resid;
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+#ifndef VITA_DMA_CFG
+#define VITA_DMA_CFG 0
+#endif
+#if VITA_DMA_CFG == 0
+    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
+    return launch_dma<64, 128, 32, 4>(p, stream);
+#elif VITA_DMA_CFG == 1
+    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
+    return launch_dma<64, 128, 64, 3>(p, stream);
+#elif VITA_DMA_CFG == 2
+    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
+    return launch_dma<64, 128, 32, 6>(p, stream);
+#else
+    return launch_dma<64, 128, 64, 3>(p, stream);
+#endif
+}
+
+bool gemm_f32_dma_eligible(const vita_linear_args& a) {
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (a.K % 4 != 0 || a.ldx % 4 != 0 || a.ldw % 4 != 0 || !al(a.X) || !al(a.W)) return false;
+    if (a.pro != VITA_PRO_NONE) {
+        if (a.ld_pro_mul != 0 || a.ld_pro_add != 0) return false;
+        if (!al(a.pro_mul) || !al(a.pro_add)) return false;
+        if (a.K > 2048) return false;
+    }
+    return true;
+}
+
+}  // namespace vita

@@ -329,6 +329,27 @@ def normalize(x, mean, std): return _norm("vita_normalize_f32", x, mean, std)
 def unnormalize(x, mean, std): return _norm("vita_unnormalize_f32", x, mean, std)
 
 
+def layernorm_modulate(x: Tensor, mul: Tensor, add: Tensor, eps: float, mode: int = L.PRO_LN_MOD) -> Tensor:
+    """LN(x)*(1+mul)+add (PRO_LN_MOD, simple_flow_net.py:44-45) or LN(x)*mul+add (PRO_LN_AFFINE, :81,106)."""
+    lib = L.load()
+    x = _rows(x, "layernorm_modulate: x")
+    M, H = x.shape
+    y = torch.empty((M, H), dtype=torch.float32, device=x.device)
+    args = []
+    for name, t in (("mul", mul), ("add", add)):
+        _f32(t, "layernorm_modulate: " + name)
+        if t.dim() == 1:
+            t = t.contiguous()
+            args.append((t, 0))
+        else:
+            t = _rows(t, "layernorm_modulate: " + name)
+            args.append((t, _ld(t)))
+    L.check(lib.vita_layernorm_modulate_f32(x.data_ptr(), _ld(x), y.data_ptr(), H, M, H, eps, mode,
+                                            args[0][0].data_ptr(), args[0][1], args[1][0].data_ptr(), args[1][1],
+                                            _stream(x)), "vita_layernorm_modulate_f32")
+    return y
+
+
 def sinusoidal_embed(t: Tensor, dim: int) -> Tensor:
     lib = L.load()
     t = _f32(t, "sinusoidal_embed").contiguous()
