@@ -3,7 +3,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := vita_amd/csrc
-SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_gemm_f32_dma.hip $(CSRC)/vita_elementwise.hip
+SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_gemm_f32_dma.hip $(CSRC)/vita_gemm_f32_t.hip $(CSRC)/vita_elementwise.hip $(CSRC)/vita_train.hip
 HDRS  := $(CSRC)/vita_common.h include/vita_hip.h
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vita_amd/libvita_hip.so

@@ -67,6 +67,8 @@ const char* vita_last_error(void);
  * per-row t in training): `x + mlp(x_norm).mul_(gamma)` simple_flow_net.py:46.  With
  * use_gate_scalar the gate is the scalar `gate_scalar`: `x + vt*dt` flow_matchers.py:71.
  * Y may alias resid.  Y must not alias X or W.
+ * With a_col / b_col the same kernel family serves the backward passes of every nn.Linear on the
+ * path (autograd of F.linear): dX = dY.W (b_col), dW += dY^T.X (a_col and b_col, resid = Y = dW).
  * --------------------------------------------------------------------------------------- */
 typedef struct vita_linear_args {
     const float* X; int64_t ldx;
@@ -82,6 +84,10 @@ typedef struct vita_linear_args {
     const float* gate; int64_t ld_gate;       /* NULL = none */
     int32_t use_gate_scalar; float gate_scalar;
     const float* resid; int64_t ld_resid;     /* NULL = none */
+    /* training-time extras (all zero/NULL for inference) */
+    float* preact; int64_t ld_preact;         /* optional (M,N): receives A'.W^T + bias BEFORE act/gate (saved for backward) */
+    int32_t a_col;  /* 1: X is stored (K,M) row-major, i.e. the GEMM contracts over X's ROWS (wgrad: dW = dY^T . X) */
+    int32_t b_col;  /* 1: W is stored (K,N) row-major, i.e. contracts over W's ROWS (dgrad: dX = dY . W)          */
 } vita_linear_args;
 
 int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream);
@@ -178,10 +184,15 @@ int vita_l1_loss_fwd_f32(const float* a, const float* b, int64_t n, float* parti
 int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout,
                          float* grad_a, float* grad_b, vita_stream_t stream);
 /* Fused CFM interpolation (torchcfm sample_location_and_conditional_flow, called at
- * flow_matchers.py:34, sigma = 0): xt = t*x1 + (1-t)*x0, ut = x1 - x0, rows of x1 optionally
- * gathered through pair_j (int64, the OT re-pairing; NULL = identity).  x0,x1,xt,ut (B,D); t (B). */
-int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_j,
+ * flow_matchers.py:34, sigma = 0): xt = t*x1[j] + (1-t)*x0[i], ut = x1[j] - x0[i]; pair_i / pair_j
+ * (int64, B entries each, or NULL = identity) are the minibatch-OT re-pairing of the `exact`
+ * matcher (drawn with replacement, so an index may repeat).  x0,x1,xt,ut (B,D); t (B). */
+int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_i, const int64_t* pair_j,
                              float* xt, float* ut, int32_t B, int32_t D, vita_stream_t stream);
+/* its backward: dx0[i] += (1-t)*dxt - dut, dx1[j] += t*dxt + dut (float atomics when an index
+ * array is given — repeated indices make the summation order, hence the last bits, run-dependent). */
+int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float* t, const int64_t* pair_i, const int64_t* pair_j,
+                                 float* dx0, float* dx1, int32_t B, int32_t D, vita_stream_t stream);
 
 /* (x - mean) / (std + 1e-8) and x*std + mean over the last dim C, broadcast over rows:
  * Normalize.forward / Unnormalize.forward, normalize.py:38-46,62-70. */
@@ -197,6 +208,43 @@ int vita_layernorm_modulate_f32(const float* x, int64_t ldx, float* y, int64_t l
 
 /* Sinusoidal time embedding, pos_embed.py:11-18: t (B) -> (B, dim) = cat(sin(t f), cos(t f)). */
 int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B, int32_t dim, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Backward-pass and optimizer kernels (autograd of the ops above; the reference gets these from
+ * torch.autograd: loss.backward() at policy_trainer.py:82).
+ * --------------------------------------------------------------------------------------- */
+/* y = act(z), and dz = dy * act'(z) from the saved pre-activation */
+int vita_act_fwd_f32(const float* z, float* y, int64_t n, int32_t act, vita_stream_t stream);
+int vita_act_bwd_f32(const float* z, const float* dy, float* dz, int64_t n, int32_t act, vita_stream_t stream);
+/* y = r + z*g  (simple_flow_net.py:46, flow_matchers.py:71):  dz = dy*g, dgate_rows = dy*z (M,N).
+ * gate: (N) vector (ld_gate 0), (M,N) matrix, or NULL = the scalar gate_scalar.  dz / dgate_rows may be NULL. */
+int vita_gate_bwd_f32(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz,
+                      float* dgate_rows, int32_t M, int32_t N, vita_stream_t stream);
+/* backward of vita_layernorm_modulate_f32: dx (M,H), and per-row dmul_rows = dy*n, dadd_rows = dy
+ * (contiguous (M,H), either may be NULL; reduce them with vita_colsum_f32 when mul/add are vectors). */
+int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul,
+                                    int32_t M, int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, float* dmul_rows,
+                                    float* dadd_rows, vita_stream_t stream);
+/* out[n] (+)= sum_m x[m,n] — bias gradients and broadcast-parameter gradients; deterministic.
+ * partials: caller scratch of vita_colsum_partials_count(N) floats. */
+int64_t vita_colsum_partials_count(int32_t N);
+int vita_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* partials, float* out, int32_t accumulate, vita_stream_t stream);
+/* Conv1d(k=5, s=2, p=2) of CNNActionEncoder (action_ae.py:301-306) as a GEMM on channels-last data:
+ * x (B,Lin,C) -> col (B*Lout, C*5), Lout = (Lin-1)/2+1, col[(b,lo), c*5+kk] = x[b, 2lo+kk-2, c];
+ * the conv weight (Cout,Cin,5) is then the (Cout, Cin*5) matrix of vita_linear_f32.  col2im is its adjoint. */
+int vita_im2col_k5s2_f32(const float* x, float* col, int32_t B, int32_t Lin, int32_t C, vita_stream_t stream);
+int vita_col2im_k5s2_f32(const float* dcol, float* dx, int32_t B, int32_t Lin, int32_t C, vita_stream_t stream);
+/* (B,L,C) -> (B,C,L) when to_ncl else the inverse: the x.view(B,-1) order of action_ae.py:323 */
+int vita_nlc_ncl_f32(const float* in, float* out, int32_t B, int32_t L, int32_t C, int32_t to_ncl, vita_stream_t stream);
+/* sum of squares of a flat buffer (gradient norm^2), deterministic; partials: vita_loss_partials_count() floats */
+int vita_sumsq_f32(const float* x, int64_t n, float* partials, float* out, vita_stream_t stream);
+/* One fused pass over flat fp32 buffers: g *= grad_scale * min(1, max_norm/(sqrt(*gnorm_sq)*grad_scale + 1e-6))
+ * (clip_grad_norm_, policy_trainer.py:83-87; gnorm_sq NULL or max_norm <= 0 = no clipping), AdamW
+ * (vita_policy.py:222-229; `step` is 1-based), then ema -= (1-ema_decay)*(ema - p) when ema != NULL
+ * (diffusers EMAModel.step, base_policy.py:45-49; policy_trainer.py:90-94). */
+int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq, float max_norm,
+                            float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                            float ema_decay, vita_stream_t stream);
 
 #ifdef __cplusplus
 }

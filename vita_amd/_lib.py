@@ -31,6 +31,8 @@ class LinearArgs(C.Structure):
         ("gate", c_fp), ("ld_gate", C.c_int64),
         ("use_gate_scalar", C.c_int32), ("gate_scalar", C.c_float),
         ("resid", c_fp), ("ld_resid", C.c_int64),
+        ("preact", c_fp), ("ld_preact", C.c_int64),
+        ("a_col", C.c_int32), ("b_col", C.c_int32),
     ]
 
 
@@ -85,7 +87,21 @@ SIGNATURES = {
     "vita_mse_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     "vita_l1_loss_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
     "vita_l1_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
-    "vita_cfm_interpolate_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_cfm_interpolate_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_cfm_interpolate_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_act_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
+    "vita_act_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
+    "vita_gate_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int64, C.c_float, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_layernorm_modulate_bwd_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32,
+                                                  C.c_float, C.c_int32, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
+    "vita_colsum_partials_count": (C.c_int64, [C.c_int32]),
+    "vita_colsum_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int32, c_fp]),
+    "vita_im2col_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),
+    "vita_col2im_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),
+    "vita_nlc_ncl_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_fp]),
+    "vita_sumsq_f32": (C.c_int, [c_fp, C.c_int64, c_fp, c_fp, c_fp]),
+    "vita_adamw_ema_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, c_fp, C.c_float, C.c_float, C.c_float,
+                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

@@ -120,14 +120,16 @@ static int loss_bwd(const float* a, const float* b, int64_t n, const float* gout
 
 // ---- CFM interpolation ---------------------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void cfm_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
-                                                       const float* __restrict__ t, const int64_t* __restrict__ pj,
-                                                       float* __restrict__ xt, float* __restrict__ ut, int B, int D) {
+                                                       const float* __restrict__ t, const int64_t* __restrict__ pi,
+                                                       const int64_t* __restrict__ pj, float* __restrict__ xt, float* __restrict__ ut,
+                                                       int B, int D) {
     const int64_t n = (int64_t)B * D;
     const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
         const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const int64_t r0 = pi ? pi[r] : r;
         const int64_t r1 = pj ? pj[r] : r;
-        const float a = x0[i], b = x1[r1 * D + c], tt = t[r];
+        const float a = x0[r0 * D + c], b = x1[r1 * D + c], tt = t[r];
         xt[i] = tt * b + (1.0f - tt) * a;   // torchcfm: t*x1 + (1-t)*x0  (sigma = 0)
         ut[i] = b - a;
     }
@@ -282,12 +284,12 @@ int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float*
     return loss_bwd<true>(a, b, n, gout, ga, gb, (hipStream_t)stream, "vita_l1_loss_bwd_f32");
 }
 
-int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_j, float* xt, float* ut,
-                             int32_t B, int32_t D, vita_stream_t stream) {
+int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_i, const int64_t* pair_j, float* xt,
+                             float* ut, int32_t B, int32_t D, vita_stream_t stream) {
     VITA_REQUIRE(x0 && x1 && t && xt && ut, "vita_cfm_interpolate_f32: null pointer");
     VITA_REQUIRE(B >= 0 && D > 0, "vita_cfm_interpolate_f32: bad shape B=%d D=%d", B, D);
     if (B == 0) return VITA_OK;
-    hipLaunchKernelGGL(cfm_kernel, dim3(ew_grid((int64_t)B * D)), dim3(EW_THREADS), 0, (hipStream_t)stream, x0, x1, t, pair_j, xt,
+    hipLaunchKernelGGL(cfm_kernel, dim3(ew_grid((int64_t)B * D)), dim3(EW_THREADS), 0, (hipStream_t)stream, x0, x1, t, pair_i, pair_j, xt,
                        ut, B, D);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;

@@ -35,6 +35,7 @@ struct GemmParams {
     const float* gate; int64_t ld_gate;
     int use_gate_scalar; float gate_scalar;
     const float* resid; int64_t ld_resid;
+    float* preact; int64_t ld_preact;
     int tiles_m, tiles_n;
     int vec_x, vec_w, vec_p;  // 16-byte vector loads legal for X / W / pro vectors
 };
@@ -289,7 +290,9 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < p.M && col_ok) {
-                        float v = apply_act_t<ACT>(acc[i][j][r] + bias);
+                        const float z = acc[i][j][r] + bias;
+                        if (p.preact != nullptr) p.preact[(int64_t)row * p.ld_preact + col] = z;
+                        float v = apply_act_t<ACT>(z);
                         if (has_gate) {
                             const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
                             v = v * g;
@@ -333,12 +336,15 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream);
+int gemm_f32_t(const vita_linear_args& a, hipStream_t stream);
 bool gemm_f32_dma_eligible(const vita_linear_args& a);
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     if (a.M == 0 && a.N > 0 && a.K > 0) return VITA_OK;  // empty batch: nothing to do (pointers may be null)
     VITA_REQUIRE(a.X && a.W && a.Y, "vita_linear_f32: X, W and Y must be non-null");
     VITA_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "vita_linear_f32: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    VITA_REQUIRE(a.preact == nullptr || a.ld_preact >= a.N, "vita_linear_f32: ld_preact must be >= N");
+    if (a.a_col || a.b_col) return gemm_f32_t(a, stream);
     VITA_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N,
                  "vita_linear_f32: leading dimension smaller than the row (ldx=%lld ldw=%lld ldy=%lld, K=%d N=%d)",
                  (long long)a.ldx, (long long)a.ldw, (long long)a.ldy, a.K, a.N);
@@ -366,6 +372,7 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     p.gate = a.gate; p.ld_gate = a.ld_gate;
     p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
     p.resid = a.resid; p.ld_resid = a.ld_resid;
+    p.preact = a.preact; p.ld_preact = a.ld_preact;
     p.vec_x = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X);
     p.vec_w = (a.K % 4 == 0) && (a.ldw % 4 == 0) && aligned16(a.W);
     p.vec_p = (a.pro != VITA_PRO_NONE) && (a.K % 4 == 0) && (a.ld_pro_mul % 4 == 0) && (a.ld_pro_add % 4 == 0) &&

@@ -43,6 +43,7 @@ struct GemmParamsDma {
     const float* gate; int64_t ld_gate;
     int use_gate_scalar; float gate_scalar;
     const float* resid; int64_t ld_resid;
+    float* preact; int64_t ld_preact;
     int tiles_m, tiles_n;
 };
 
@@ -326,7 +327,9 @@ __global__ __launch_bounds__(DNT) void gemm_f32_dma_kernel(GemmParamsDma p) {
                 for (int r = 0; r < 16; ++r) {
                     const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                     if (row < p.M && col_ok) {
-                        float v = apply_act_t<ACT>(acc[i][j][r] + bias);
+                        const float z = acc[i][j][r] + bias;
+                        if (p.preact != nullptr) p.preact[(int64_t)row * p.ld_preact + col] = z;
+                        float v = apply_act_t<ACT>(z);
                         if (has_gate) {
                             const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
                             v = v * g;
@@ -373,6 +376,7 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
     p.gate = a.gate; p.ld_gate = a.ld_gate;
     p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
     p.resid = a.resid; p.ld_resid = a.ld_resid;
+    p.preact = a.preact; p.ld_preact = a.ld_preact;
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
 #ifndef VITA_DMA_CFG
 #define VITA_DMA_CFG 0

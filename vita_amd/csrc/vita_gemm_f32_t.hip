@@ -1,0 +1,244 @@
+// fp32 MFMA GEMM with transposed ("column") operands — the backward passes of nn.Linear.
+//
+//   C[M,N] = resid + gate_scalar * ( sum_k A(m,k) * B(n,k) + bias )
+//     a_col = 0 : A(m,k) = X[m*ldx + k]        a_col = 1 : A(m,k) = X[k*ldx + m]
+//     b_col = 0 : B(n,k) = W[n*ldw + k]        b_col = 1 : B(n,k) = W[k*ldw + n]
+//
+//   dgrad  dX[B,in]   = dY[B,out] . W[out,in]          -> a_col=0, b_col=1, K=out
+//   wgrad  dW[out,in] += dY[B,out]^T . X[B,in]         -> a_col=1, b_col=1, K=B, resid = Y = dW
+//
+// Same skeleton as vita_gemm_f32.hip (512 threads, 2x4 waves of 32x32 MFMA tiles, ring of three
+// LDS buffers, fragments one chunk ahead).  A column operand is staged as [BK][rows+4]: the
+// global rows are contiguous along m (or n), so the staging loads stay 16-byte coalesced, and
+// the fragment read becomes four ds_read_b32 (32 consecutive dwords per half-wave:
+// conflict-free) with the same k pairing (8c + 4h + j) the row operand's ds_read_b128 gives.
+#include <type_traits>
+
+#include "vita_common.h"
+
+namespace vita {
+
+struct GemmParamsT {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    const float* bias;
+    float* Y; int64_t ldy;
+    int M, N, K;
+    int use_gate_scalar; float gate_scalar;
+    const float* resid; int64_t ld_resid;
+    int tiles_m, tiles_n;
+};
+
+constexpr int TNT = 512;
+__device__ __attribute__((aligned(16))) float g_zero_t[4] = {0.f, 0.f, 0.f, 0.f};
+
+// Stage descriptor of one operand tile: ROWS output rows (m or n) x BK reduction elements.
+template <int ROWS, int BK, bool COL>
+struct OpTile {
+    static constexpr int S = COL ? ROWS + 4 : BK + 4;                  // LDS row stride (floats)
+    static constexpr int BUF = COL ? BK * S : ROWS * S;                // floats per buffer
+    static constexpr int PER_ROW = COL ? ROWS / 4 : BK / 4;            // float4 slots per LDS row
+    static constexpr int SLOTS = ROWS * BK / 4 / TNT;
+};
+
+template <int BM, int BN, int BK, bool ACOL, bool BCOL, bool VEC>
+__global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
+    using TA = OpTile<BM, BK, ACOL>;
+    using TB = OpTile<BN, BK, BCOL>;
+    constexpr int TM = BM / 2, TN = BN / 4;
+    constexpr int MI = TM / 32, NI = TN / 32;
+    constexpr int NCH = BK / 8;
+    static_assert(TA::SLOTS >= 1 && TB::SLOTS >= 1 && MI >= 1 && NI >= 1 && NCH % 2 == 0, "bad tile");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                   // [3][TA::BUF]
+    float* Bs = smem + 3 * TA::BUF;     // [3][TB::BUF]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+    }
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int K = p.K;
+    const int nk = (K + BK - 1) / BK;
+
+    // slot geometry: (r, c) = LDS row / float offset in the row
+    auto slot_rc = [&](int s, int per_row, int& r, int& c) { r = s / per_row; c = (s % per_row) * 4; };
+
+    f32x4 a_reg[TA::SLOTS], b_reg[TB::SLOTS];
+    auto load_tile = [&](auto tile_tag, const float* base, int64_t ld, int o0, int lim, int kt, auto& regs) {
+        using T = decltype(tile_tag);
+        constexpr bool COL = std::is_same<T, TA>::value ? ACOL : BCOL;
+#pragma unroll
+        for (int i = 0; i < T::SLOTS; ++i) {
+            int r, c;
+            slot_rc(tid + i * TNT, T::PER_ROW, r, c);
+            f32x4 v;
+            if constexpr (COL) {      // LDS row r = k, c = offset along the output dim
+                const int k = kt * BK + r, o = o0 + c;
+                const float* src = base + (int64_t)k * ld + o;
+                if constexpr (VEC) {
+                    v = *reinterpret_cast<const f32x4*>((k < K && o < lim) ? src : g_zero_t);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = *((k < K && o + j < lim) ? src + j : g_zero_t);
+                }
+            } else {                  // LDS row r = output row, c = k offset
+                const int k = kt * BK + c;
+                const float* src = base + (int64_t)min(o0 + r, lim - 1) * ld + k;
+                if constexpr (VEC) {
+                    v = *reinterpret_cast<const f32x4*>(k < K ? src : g_zero_t);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = *((k + j < K) ? src + j : g_zero_t);
+                }
+            }
+            regs[i] = v;
+        }
+    };
+    auto store_tile = [&](auto tile_tag, float* lds, const auto& regs) {
+        using T = decltype(tile_tag);
+#pragma unroll
+        for (int i = 0; i < T::SLOTS; ++i) {
+            int r, c;
+            slot_rc(tid + i * TNT, T::PER_ROW, r, c);
+            *reinterpret_cast<f32x4*>(lds + r * T::S + c) = regs[i];
+        }
+    };
+    auto issue_loads = [&](int kt) {
+        load_tile(TA{}, p.X, p.ldx, m0, p.M, kt, a_reg);
+        load_tile(TB{}, p.W, p.ldw, n0, p.N, kt, b_reg);
+    };
+    auto write_lds = [&](int buf) {
+        store_tile(TA{}, As + buf * TA::BUF, a_reg);
+        store_tile(TB{}, Bs + buf * TB::BUF, b_reg);
+    };
+
+    const int fr = lane & 31, fh = lane >> 5;
+    f32x4 af[2][MI], bf[2][NI];
+    auto read_frags = [&](int buf, int kc, f32x4 (&a)[MI], f32x4 (&b)[NI]) {
+        const float* A = As + buf * TA::BUF;
+        const float* B = Bs + buf * TB::BUF;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int row = wm * TM + i * 32 + fr;
+            if constexpr (ACOL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[i][e] = A[(kc * 8 + fh * 4 + e) * TA::S + row];
+            } else {
+                a[i] = *reinterpret_cast<const f32x4*>(A + row * TA::S + kc * 8 + fh * 4);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = wn * TN + j * 32 + fr;
+            if constexpr (BCOL) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) b[j][e] = B[(kc * 8 + fh * 4 + e) * TB::S + row];
+            } else {
+                b[j] = *reinterpret_cast<const f32x4*>(B + row * TB::S + kc * 8 + fh * 4);
+            }
+        }
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue_loads(0);
+    write_lds(0);
+    issue_loads(1);   // beyond K every element comes from the zero page
+    write_lds(1);
+    issue_loads(2);
+    __syncthreads();
+    read_frags(0, 0, af[0], bf[0]);
+
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf1 = buf == 2 ? 0 : buf + 1;
+        const int buf2 = buf1 == 2 ? 0 : buf1 + 1;
+#pragma unroll
+        for (int kc = 0; kc < NCH; ++kc) {
+            if (kc == 1) write_lds(buf2);
+            if (kc == 2) issue_loads(kt + 3);
+            if (kc + 1 < NCH) read_frags(buf, kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1]);
+            else read_frags(buf1, 0, af[0], bf[0]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][i][e], bf[kc & 1][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+        buf = buf1;
+    }
+
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int col = n0 + wn * TN + j * 32 + (lane & 31);
+        const bool col_ok = col < p.N;
+        const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < p.M && col_ok) {
+                    float v = acc[i][j][r] + bias;
+                    if (p.use_gate_scalar) v = v * p.gate_scalar;
+                    if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
+                    p.Y[(int64_t)row * p.ldy + col] = v;
+                }
+            }
+    }
+}
+
+template <bool ACOL, bool BCOL>
+static int launch_t(GemmParamsT p, bool vec, hipStream_t stream) {
+    constexpr int BM = 64, BN = 128, BK = 32;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = (size_t)3 * (OpTile<BM, BK, ACOL>::BUF + OpTile<BN, BK, BCOL>::BUF) * sizeof(float);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(TNT);
+    if (vec) hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, BK, ACOL, BCOL, true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, BK, ACOL, BCOL, false>), grid, block, lds, stream, p);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+int gemm_f32_t(const vita_linear_args& a, hipStream_t stream) {
+    const char* who = "vita_linear_f32 (transposed operands)";
+    VITA_REQUIRE(a.X && a.W && a.Y, "%s: X, W and Y must be non-null", who);
+    VITA_REQUIRE(a.M > 0 && a.N > 0 && a.K >= 0, "%s: bad shape M=%d N=%d K=%d", who, a.M, a.N, a.K);
+    VITA_REQUIRE(a.ldx >= (a.a_col ? a.M : a.K) && a.ldw >= (a.b_col ? a.N : a.K) && a.ldy >= a.N, "%s: leading dimension too small", who);
+    VITA_REQUIRE(a.pro == VITA_PRO_NONE && a.act == VITA_ACT_NONE && a.gate == nullptr && a.preact == nullptr,
+                 "%s: prologue / activation / vector gate / preact are not available with a_col or b_col", who);
+    VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "%s: ld_resid must be >= N", who);
+    VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W, "%s: Y must not alias X or W", who);
+    GemmParamsT p{};
+    p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias; p.Y = a.Y; p.ldy = a.ldy;
+    p.M = a.M; p.N = a.N; p.K = a.K;
+    p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
+    p.resid = a.resid; p.ld_resid = a.ld_resid;
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    const bool vx = al(a.X) && a.ldx % 4 == 0 && (a.a_col ? a.M % 4 == 0 : a.K % 4 == 0);
+    const bool vw = al(a.W) && a.ldw % 4 == 0 && (a.b_col ? a.N % 4 == 0 : a.K % 4 == 0);
+    const bool vec = vx && vw;
+    if (a.a_col && a.b_col) return launch_t<true, true>(p, vec, stream);
+    if (a.a_col) return launch_t<true, false>(p, vec, stream);
+    return launch_t<false, true>(p, vec, stream);
+}
+
+}  // namespace vita

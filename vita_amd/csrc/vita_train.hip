@@ -1,0 +1,376 @@
+// Training-side elementwise / reduction kernels: activation and LayerNorm backward, gate
+// backward, column sums (bias and broadcast-parameter gradients), conv1d im2col/col2im, CFM
+// interpolation backward, and the fused clip + AdamW + EMA update.  All HBM-bound: 16-byte
+// accesses where alignment allows, wave64 shuffle reductions, deterministic two-stage sums.
+#include "vita_common.h"
+
+namespace vita {
+
+constexpr int TT = 256;
+static inline int tgrid(int64_t items, int cap = 4096) {
+    int64_t b = (items + TT - 1) / TT;
+    return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+
+// ---- activation derivative --------------------------------------------------------------------
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case VITA_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case VITA_ACT_GELU_ERF: {   // torch GeluBackward (none): cdf + z*pdf
+            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+            const float pdf = expf(-0.5f * z * z) * 0.3989422804014327f;
+            return cdf + z * pdf;
+        }
+        case VITA_ACT_GELU_TANH: {  // torch GeluBackward (tanh)
+            const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+            const float z2 = z * z;
+            const float inner = kBeta * (z + kKappa * z2 * z);
+            const float th = tanhf(inner);
+            const float left = 0.5f * z, right = 1.0f + th;
+            const float dleft = 0.5f;
+            const float dth = 1.0f - th * th;
+            const float dinner = kBeta * (1.0f + 3.0f * kKappa * z2);
+            return dleft * right + left * (dth * dinner);
+        }
+        case VITA_ACT_SILU: {
+            const float s = 1.0f / (1.0f + expf(-z));
+            return s * (1.0f + z * (1.0f - s));
+        }
+        case VITA_ACT_MISH: {       // d/dz z*tanh(softplus(z)) = tanh(sp) + z*sigmoid(z)*(1-tanh(sp)^2)
+            const float sp = z > 20.0f ? z : log1pf(expf(z));
+            const float th = tanhf(sp);
+            const float s = 1.0f / (1.0f + expf(-z));
+            return th + z * s * (1.0f - th * th);
+        }
+        default: return 1.f;
+    }
+}
+
+__global__ __launch_bounds__(TT) void act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy, float* __restrict__ dz,
+                                                    int64_t n, int act) {
+    const int64_t stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) dz[i] = dy[i] * act_grad(z[i], act);
+}
+__global__ __launch_bounds__(TT) void act_fwd_kernel(const float* __restrict__ z, float* __restrict__ y, int64_t n, int act) {
+    const int64_t stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) y[i] = apply_act(z[i], act);
+}
+
+// ---- gate backward: y = r + z*g ------------------------------------------------------------------
+// dz = dy*g ; dg_rows = dy*z (optional).  g: vector (ld_g = 0), matrix (ld_g >= N) or scalar (g == NULL).
+__global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ g,
+                                                     int64_t ld_g, float gs, float* __restrict__ dz, float* __restrict__ dg, int M, int N) {
+    const int64_t n = (int64_t)M * N, stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / N), c = (int)(i - (int64_t)r * N);
+        const float d = dy[i];
+        const float gv = g ? g[(int64_t)r * ld_g + c] : gs;
+        if (dz) dz[i] = d * gv;
+        if (dg) dg[i] = d * z[i];
+    }
+}
+
+// ---- LayerNorm(+modulation) backward, one wave per row --------------------------------------------
+constexpr int LNB_MAXC = 8;
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t ldd,
+                                                         const float* __restrict__ mul, int64_t ld_mul, int M, int H, float eps, int mod,
+                                                         float* __restrict__ dx, int64_t ld_dx, float* __restrict__ dmul, float* __restrict__ dadd) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const float* dr = dy + (int64_t)row * ldd;
+    const float* mr = mul + (int64_t)row * ld_mul;
+    float v[LNB_MAXC * 4], d[LNB_MAXC * 4];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < LNB_MAXC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = (c * 64 + lane) * 4 + j;
+            v[c * 4 + j] = k < H ? xr[k] : 0.f;
+            s += v[c * 4 + j];
+        }
+    s = wave_sum(s);
+    const float mu = s / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int c = 0; c < LNB_MAXC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = (c * 64 + lane) * 4 + j;
+            const float t = k < H ? v[c * 4 + j] - mu : 0.f;
+            q = fmaf(t, t, q);
+        }
+    q = wave_sum(q);
+    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
+    // n = (x-mu)*rstd ; dn = dy*m ; s1 = mean(dn) ; s2 = mean(dn*n) ; dx = rstd*(dn - s1 - n*s2)
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < LNB_MAXC; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = (c * 64 + lane) * 4 + j;
+            if (k < H) {
+                const float nrm = (v[c * 4 + j] - mu) * rstd;
+                const float g = dr[k];
+                const float m = mod ? (mr[k] + 1.0f) : mr[k];
+                const float dn = g * m;
+                if (dmul) dmul[(int64_t)row * H + k] = g * nrm;
+                if (dadd) dadd[(int64_t)row * H + k] = g;
+                v[c * 4 + j] = nrm;
+                d[c * 4 + j] = dn;
+                s1 += dn;
+                s2 = fmaf(dn, nrm, s2);
+            } else {
+                v[c * 4 + j] = 0.f;
+                d[c * 4 + j] = 0.f;
+            }
+        }
+    s1 = wave_sum(s1) / (float)H;
+    s2 = wave_sum(s2) / (float)H;
+    if (dx) {
+#pragma unroll
+        for (int c = 0; c < LNB_MAXC; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = (c * 64 + lane) * 4 + j;
+                if (k < H) dx[(int64_t)row * ld_dx + k] = rstd * (d[c * 4 + j] - s1 - v[c * 4 + j] * s2);
+            }
+    }
+}
+
+// ---- column sums: out[n] (+)= sum_m x[m,n]; two deterministic stages --------------------------------
+constexpr int CS_R = 64;   // row splits == partial rows; vita_colsum_partials_count(N) = CS_R * N
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ x, int64_t ldx, int M, int N, float* __restrict__ part) {
+    // block: 64 columns x 4 row lanes; blockIdx.y = row split
+    const int col = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int rows_per = (M + CS_R - 1) / CS_R;
+    const int r0 = blockIdx.y * rows_per, r1 = min(M, r0 + rows_per);
+    float s = 0.f;
+    if (col < N)
+        for (int r = r0 + rl; r < r1; r += 4) s += x[(int64_t)r * ldx + col];
+    __shared__ float sh[4][64];
+    sh[rl][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (rl == 0 && col < N) part[(int64_t)blockIdx.y * N + col] = (sh[0][threadIdx.x] + sh[1][threadIdx.x]) + (sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int N, float* __restrict__ out, int accumulate) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= N) return;
+    float s = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < CS_R; ++r) s += part[(int64_t)r * N + col];
+    out[col] = accumulate ? out[col] + s : s;
+}
+
+// ---- conv1d(k=5, s=2, p=2) as a GEMM: im2col / col2im on channels-last activations ------------------
+// x (B, Lin, C) -> col (B*Lout, C*5), col[(b,lo), c*5+kk] = x[b, 2*lo+kk-2, c] (0 outside), so the
+// checkpoint weight (Cout, Cin, 5) viewed as (Cout, Cin*5) is used unchanged (action_ae.py:303-305).
+__global__ __launch_bounds__(TT) void im2col_kernel(const float* __restrict__ x, float* __restrict__ col, int B, int Lin, int Lout, int C) {
+    const int64_t n = (int64_t)B * Lout * C * 5, stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        const int kk = (int)(i % 5);
+        const int c = (int)((i / 5) % C);
+        const int64_t row = i / (5 * (int64_t)C);
+        const int lo = (int)(row % Lout), b = (int)(row / Lout);
+        const int t = 2 * lo + kk - 2;
+        col[i] = (t >= 0 && t < Lin) ? x[((int64_t)b * Lin + t) * C + c] : 0.f;
+    }
+}
+// dx[b,t,c] = sum over (lo,kk) with 2*lo+kk-2 == t of dcol[(b,lo), c*5+kk]   (a gather: deterministic)
+__global__ __launch_bounds__(TT) void col2im_kernel(const float* __restrict__ dcol, float* __restrict__ dx, int B, int Lin, int Lout, int C) {
+    const int64_t n = (int64_t)B * Lin * C, stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        const int c = (int)(i % C);
+        const int t = (int)((i / C) % Lin);
+        const int b = (int)(i / ((int64_t)C * Lin));
+        float s = 0.f;
+#pragma unroll
+        for (int kk = 0; kk < 5; ++kk) {
+            const int u = t + 2 - kk;
+            if (u >= 0 && (u & 1) == 0 && (u >> 1) < Lout) s += dcol[(((int64_t)b * Lout + (u >> 1)) * C + c) * 5 + kk];
+        }
+        dx[i] = s;
+    }
+}
+// (B, L, C) <-> (B, C, L) flatten order (x.view(B,-1) on the (B,C,L) conv output, action_ae.py:323)
+__global__ __launch_bounds__(TT) void nlc_ncl_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int L, int C, int to_ncl) {
+    const int64_t n = (int64_t)B * L * C, stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        // i indexes the OUTPUT
+        if (to_ncl) {
+            const int l = (int)(i % L), c = (int)((i / L) % C), b = (int)(i / ((int64_t)L * C));
+            out[i] = in[((int64_t)b * L + l) * C + c];
+        } else {
+            const int c = (int)(i % C), l = (int)((i / C) % L), b = (int)(i / ((int64_t)L * C));
+            out[i] = in[((int64_t)b * C + c) * L + l];
+        }
+    }
+}
+
+// ---- CFM interpolation backward --------------------------------------------------------------------
+// xt = t*x1[j] + (1-t)*x0[i], ut = x1[j]-x0[i]  =>  dx0[i] += (1-t)*dxt - dut ; dx1[j] += t*dxt + dut
+__global__ __launch_bounds__(TT) void cfm_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ dut, const float* __restrict__ t,
+                                                    const int64_t* __restrict__ pi, const int64_t* __restrict__ pj, float* __restrict__ dx0,
+                                                    float* __restrict__ dx1, int B, int D) {
+    const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const float a = dxt ? dxt[i] : 0.f, u = dut ? dut[i] : 0.f, tt = t[r];
+        const float g0 = (1.0f - tt) * a - u, g1 = tt * a + u;
+        if (dx0) { if (pi) atomicAdd(&dx0[pi[r] * D + c], g0); else dx0[i] = g0; }
+        if (dx1) { if (pj) atomicAdd(&dx1[pj[r] * D + c], g1); else dx1[i] = g1; }
+    }
+}
+
+// ---- sum of squares (gradient norm), two-stage ------------------------------------------------------
+__global__ __launch_bounds__(TT) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
+    float s = 0.f;
+    const int64_t stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) s = fmaf(x[i], x[i], s);
+    s = wave_sum(s);
+    __shared__ float ws[TT / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
+}
+__global__ __launch_bounds__(TT) void sumsq_stage2(const float* __restrict__ part, int count, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < count; i += TT) s += (double)part[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[TT / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)((ws[0] + ws[1]) + (ws[2] + ws[3]));
+}
+
+// ---- fused clip + AdamW + EMA over a flat parameter buffer -------------------------------------------
+// torch.nn.utils.clip_grad_norm_ (policy_trainer.py:83-87): coef = min(1, max_norm / (norm + 1e-6));
+// torch.optim.AdamW single-tensor update (vita_policy.py:222-229); diffusers EMAModel.step
+// (base_policy.py:45-49): ema -= (1-decay)*(ema - p).
+__global__ __launch_bounds__(TT) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                      float* __restrict__ v, float* __restrict__ ema, int64_t n, const float* __restrict__ gnorm_sq,
+                                                      float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float wd,
+                                                      float bc1, float bc2_sqrt, float ema_decay) {
+    float coef = grad_scale;
+    if (gnorm_sq != nullptr && max_norm > 0.f) {
+        const float norm = sqrtf(gnorm_sq[0]) * grad_scale;
+        const float c = max_norm / (norm + 1e-6f);
+        coef = grad_scale * (c < 1.0f ? c : 1.0f);
+    }
+    const float step_size = lr / bc1;
+    const float one_m_decay = 1.0f - ema_decay;
+    const int64_t stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);           // lerp_(g, 1-beta1)
+        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi = pi - step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+        if (ema) ema[i] = ema[i] - one_m_decay * (ema[i] - pi);
+    }
+}
+
+}  // namespace vita
+
+using namespace vita;
+
+#define LAUNCH_OK() do { VITA_CHECK_HIP(hipGetLastError()); return VITA_OK; } while (0)
+
+extern "C" {
+
+int vita_act_fwd_f32(const float* z, float* y, int64_t n, int32_t act, vita_stream_t s) {
+    VITA_REQUIRE(z && y && n >= 0 && act >= 0 && act <= VITA_ACT_MISH, "vita_act_fwd_f32: bad arguments");
+    if (n == 0) return VITA_OK;
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(tgrid(n)), dim3(TT), 0, (hipStream_t)s, z, y, n, act);
+    LAUNCH_OK();
+}
+int vita_act_bwd_f32(const float* z, const float* dy, float* dz, int64_t n, int32_t act, vita_stream_t s) {
+    VITA_REQUIRE(z && dy && dz && n >= 0 && act >= 0 && act <= VITA_ACT_MISH, "vita_act_bwd_f32: bad arguments");
+    if (n == 0) return VITA_OK;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(tgrid(n)), dim3(TT), 0, (hipStream_t)s, z, dy, dz, n, act);
+    LAUNCH_OK();
+}
+int vita_gate_bwd_f32(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz, float* dgate_rows,
+                      int32_t M, int32_t N, vita_stream_t s) {
+    VITA_REQUIRE(dy && M >= 0 && N > 0, "vita_gate_bwd_f32: bad arguments");
+    VITA_REQUIRE(dgate_rows == nullptr || z != nullptr, "vita_gate_bwd_f32: dgate needs z");
+    VITA_REQUIRE(gate == nullptr || ld_gate == 0 || ld_gate >= N, "vita_gate_bwd_f32: ld_gate must be 0 or >= N");
+    if (M == 0 || (!dz && !dgate_rows)) return VITA_OK;
+    hipLaunchKernelGGL(gate_bwd_kernel, dim3(tgrid((int64_t)M * N)), dim3(TT), 0, (hipStream_t)s, dy, z, gate, ld_gate, gate_scalar, dz,
+                       dgate_rows, M, N);
+    LAUNCH_OK();
+}
+int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul, int32_t M,
+                                    int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, float* dmul_rows, float* dadd_rows,
+                                    vita_stream_t s) {
+    VITA_REQUIRE(x && dy && mul, "vita_layernorm_modulate_bwd_f32: null pointer");
+    VITA_REQUIRE(M >= 0 && H > 0 && H <= 64 * 4 * LNB_MAXC, "vita_layernorm_modulate_bwd_f32: H=%d outside (0, %d]", H, 64 * 4 * LNB_MAXC);
+    VITA_REQUIRE(ldx >= H && ld_dy >= H && (ld_mul == 0 || ld_mul >= H) && (dx == nullptr || ld_dx >= H), "vita_layernorm_modulate_bwd_f32: bad leading dimension");
+    VITA_REQUIRE(mode == VITA_PRO_LN_MOD || mode == VITA_PRO_LN_AFFINE, "vita_layernorm_modulate_bwd_f32: bad mode");
+    if (M == 0) return VITA_OK;
+    hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)s, x, ldx, dy, ld_dy, mul, ld_mul, M, H, eps,
+                       mode == VITA_PRO_LN_MOD ? 1 : 0, dx, ld_dx, dmul_rows, dadd_rows);
+    LAUNCH_OK();
+}
+int64_t vita_colsum_partials_count(int32_t N) { return (int64_t)CS_R * (N > 0 ? N : 0); }
+int vita_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* partials, float* out, int32_t accumulate, vita_stream_t s) {
+    VITA_REQUIRE(x && partials && out && M >= 0 && N > 0 && ldx >= N, "vita_colsum_f32: bad arguments");
+    hipLaunchKernelGGL(colsum_stage1, dim3((N + 63) / 64, CS_R), dim3(256), 0, (hipStream_t)s, x, ldx, M, N, partials);
+    hipLaunchKernelGGL(colsum_stage2, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, partials, N, out, accumulate);
+    LAUNCH_OK();
+}
+int vita_im2col_k5s2_f32(const float* x, float* col, int32_t B, int32_t Lin, int32_t C, vita_stream_t s) {
+    VITA_REQUIRE(x && col && B >= 0 && Lin > 0 && C > 0, "vita_im2col_k5s2_f32: bad arguments");
+    const int Lout = (Lin - 1) / 2 + 1;
+    if (B == 0) return VITA_OK;
+    hipLaunchKernelGGL(im2col_kernel, dim3(tgrid((int64_t)B * Lout * C * 5)), dim3(TT), 0, (hipStream_t)s, x, col, B, Lin, Lout, C);
+    LAUNCH_OK();
+}
+int vita_col2im_k5s2_f32(const float* dcol, float* dx, int32_t B, int32_t Lin, int32_t C, vita_stream_t s) {
+    VITA_REQUIRE(dcol && dx && B >= 0 && Lin > 0 && C > 0, "vita_col2im_k5s2_f32: bad arguments");
+    const int Lout = (Lin - 1) / 2 + 1;
+    if (B == 0) return VITA_OK;
+    hipLaunchKernelGGL(col2im_kernel, dim3(tgrid((int64_t)B * Lin * C)), dim3(TT), 0, (hipStream_t)s, dcol, dx, B, Lin, Lout, C);
+    LAUNCH_OK();
+}
+int vita_nlc_ncl_f32(const float* in, float* out, int32_t B, int32_t L, int32_t C, int32_t to_ncl, vita_stream_t s) {
+    VITA_REQUIRE(in && out && in != out && B >= 0 && L > 0 && C > 0, "vita_nlc_ncl_f32: bad arguments");
+    if (B == 0) return VITA_OK;
+    hipLaunchKernelGGL(nlc_ncl_kernel, dim3(tgrid((int64_t)B * L * C)), dim3(TT), 0, (hipStream_t)s, in, out, B, L, C, to_ncl);
+    LAUNCH_OK();
+}
+int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float* t, const int64_t* pair_i, const int64_t* pair_j, float* dx0,
+                                 float* dx1, int32_t B, int32_t D, vita_stream_t s) {
+    VITA_REQUIRE(t && (dxt || dut) && B >= 0 && D > 0, "vita_cfm_interpolate_bwd_f32: bad arguments");
+    if (B == 0 || (!dx0 && !dx1)) return VITA_OK;
+    hipStream_t st = (hipStream_t)s;
+    if (dx0 && pair_i) VITA_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)B * D * 4, st));
+    if (dx1 && pair_j) VITA_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)B * D * 4, st));
+    hipLaunchKernelGGL(cfm_bwd_kernel, dim3(tgrid((int64_t)B * D)), dim3(TT), 0, st, dxt, dut, t, pair_i, pair_j, dx0, dx1, B, D);
+    LAUNCH_OK();
+}
+int vita_sumsq_f32(const float* x, int64_t n, float* partials, float* out, vita_stream_t s) {
+    VITA_REQUIRE(x && partials && out && n > 0, "vita_sumsq_f32: bad arguments");
+    const int blocks = tgrid(n, 1024);
+    hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(TT), 0, (hipStream_t)s, x, n, partials);
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(TT), 0, (hipStream_t)s, partials, blocks, out);
+    LAUNCH_OK();
+}
+int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq, float max_norm,
+                            float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                            float ema_decay, vita_stream_t s) {
+    VITA_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vita_adamw_ema_step_f32: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(tgrid(n)), dim3(TT), 0, (hipStream_t)s, p, g, m, v, ema, n, gnorm_sq, max_norm, grad_scale, lr,
+                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), ema_decay);
+    LAUNCH_OK();
+}
+
+}  // extern "C"

@@ -294,18 +294,22 @@ def mse_loss_bwd(a, b, g, need_a=True, need_b=True): return _loss_bwd("vita_mse_
 def l1_loss_bwd(a, b, g, need_a=True, need_b=True): return _loss_bwd("vita_l1_loss_bwd_f32", a, b, g, need_a, need_b)
 
 
-def cfm_interpolate(x0: Tensor, x1: Tensor, t: Tensor, pair_j: Optional[Tensor] = None):
-    """xt = t*x1[pair_j] + (1-t)*x0, ut = x1[pair_j] - x0 (torchcfm, sigma=0; flow_matchers.py:34)."""
+def _idx(t, device):
+    return None if t is None else t.to(device=device, dtype=torch.int64).contiguous()
+
+
+def cfm_interpolate(x0: Tensor, x1: Tensor, t: Tensor, pair_j: Optional[Tensor] = None, pair_i: Optional[Tensor] = None):
+    """xt = t*x1[pair_j] + (1-t)*x0[pair_i], ut = x1[pair_j] - x0[pair_i] (torchcfm, sigma=0; flow_matchers.py:34)."""
     lib = L.load()
     x0 = _f32(x0, "cfm_interpolate").contiguous()
     x1 = _f32(x1, "cfm_interpolate").contiguous()
     t = _f32(t, "cfm_interpolate").contiguous()
     B, D = x0.shape
-    if pair_j is not None:
-        pair_j = pair_j.to(device=x0.device, dtype=torch.int64).contiguous()
+    pair_i, pair_j = _idx(pair_i, x0.device), _idx(pair_j, x0.device)
     xt = torch.empty_like(x0)
     ut = torch.empty_like(x0)
     L.check(lib.vita_cfm_interpolate_f32(x0.data_ptr(), x1.data_ptr(), t.data_ptr(),
+                                         pair_i.data_ptr() if pair_i is not None else None,
                                          pair_j.data_ptr() if pair_j is not None else None,
                                          xt.data_ptr(), ut.data_ptr(), B, D, _stream(x0)), "vita_cfm_interpolate_f32")
     return xt, ut
