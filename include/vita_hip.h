@@ -88,6 +88,9 @@ typedef struct vita_linear_args {
     float* preact; int64_t ld_preact;         /* optional (M,N): receives A'.W^T + bias BEFORE act/gate (saved for backward) */
     int32_t a_col;  /* 1: X is stored (K,M) row-major, i.e. the GEMM contracts over X's ROWS (wgrad: dW = dY^T . X) */
     int32_t b_col;  /* 1: W is stored (K,N) row-major, i.e. contracts over W's ROWS (dgrad: dX = dY . W)          */
+    /* with a_col/b_col only: the result is multiplied by act'(act_grad_z[m,n]) — the backward of the activation that
+     * followed the previous layer, fused into this layer's dgrad (`act` names the activation).  Y may alias act_grad_z. */
+    const float* act_grad_z; int64_t ld_act_grad_z;
 } vita_linear_args;
 
 int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream);
@@ -175,14 +178,14 @@ int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O,
 int32_t vita_loss_partials_count(void);
 /* mean((a-b)^2): F.mse_loss (vita_policy.py:163) and torch.mean((vt-ut)**2) (flow_matchers.py:36) */
 int vita_mse_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream);
-/* grad_a = 2(a-b)/n * gout[0]; grad_b = -grad_a (either may be NULL) */
+/* grad_a = 2(a-b)/n * gout[0]; grad_b = -grad_a (either may be NULL); accumulate != 0 adds into grad_a / grad_b */
 int vita_mse_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout,
-                          float* grad_a, float* grad_b, vita_stream_t stream);
+                          float* grad_a, float* grad_b, int32_t accumulate, vita_stream_t stream);
 /* mean(|a-b|): F.l1_loss (vita_policy.py:67,176,185) */
 int vita_l1_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream);
 /* grad_a = sign(a-b)/n * gout[0] */
 int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout,
-                         float* grad_a, float* grad_b, vita_stream_t stream);
+                         float* grad_a, float* grad_b, int32_t accumulate, vita_stream_t stream);
 /* Fused CFM interpolation (torchcfm sample_location_and_conditional_flow, called at
  * flow_matchers.py:34, sigma = 0): xt = t*x1[j] + (1-t)*x0[i], ut = x1[j] - x0[i]; pair_i / pair_j
  * (int64, B entries each, or NULL = identity) are the minibatch-OT re-pairing of the `exact`
@@ -190,9 +193,10 @@ int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float*
 int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_i, const int64_t* pair_j,
                              float* xt, float* ut, int32_t B, int32_t D, vita_stream_t stream);
 /* its backward: dx0[i] += (1-t)*dxt - dut, dx1[j] += t*dxt + dut (float atomics when an index
- * array is given — repeated indices make the summation order, hence the last bits, run-dependent). */
+ * array is given — repeated indices make the summation order, hence the last bits, run-dependent).
+ * accumulate == 0: dx0 / dx1 are overwritten (zeroed first when indexed); != 0: added into. */
 int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float* t, const int64_t* pair_i, const int64_t* pair_j,
-                                 float* dx0, float* dx1, int32_t B, int32_t D, vita_stream_t stream);
+                                 float* dx0, float* dx1, int32_t B, int32_t D, int32_t accumulate, vita_stream_t stream);
 
 /* (x - mean) / (std + 1e-8) and x*std + mean over the last dim C, broadcast over rows:
  * Normalize.forward / Unnormalize.forward, normalize.py:38-46,62-70. */
@@ -216,15 +220,17 @@ int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B
 /* y = act(z), and dz = dy * act'(z) from the saved pre-activation */
 int vita_act_fwd_f32(const float* z, float* y, int64_t n, int32_t act, vita_stream_t stream);
 int vita_act_bwd_f32(const float* z, const float* dy, float* dz, int64_t n, int32_t act, vita_stream_t stream);
-/* y = r + z*g  (simple_flow_net.py:46, flow_matchers.py:71):  dz = dy*g, dgate_rows = dy*z (M,N).
+/* y = r + z*g  (simple_flow_net.py:46, flow_matchers.py:71):  dz = dy*g (contiguous (M,N), may alias z),
+ * dgate_rows = dy*z (M,N) with row stride ld_dgate.
  * gate: (N) vector (ld_gate 0), (M,N) matrix, or NULL = the scalar gate_scalar.  dz / dgate_rows may be NULL. */
 int vita_gate_bwd_f32(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz,
-                      float* dgate_rows, int32_t M, int32_t N, vita_stream_t stream);
-/* backward of vita_layernorm_modulate_f32: dx (M,H), and per-row dmul_rows = dy*n, dadd_rows = dy
- * (contiguous (M,H), either may be NULL; reduce them with vita_colsum_f32 when mul/add are vectors). */
+                      float* dgate_rows, int64_t ld_dgate, int32_t M, int32_t N, vita_stream_t stream);
+/* backward of vita_layernorm_modulate_f32: dx (M,H) (added into when dx_accumulate != 0: the residual
+ * branch), and per-row dmul_rows = dy*n, dadd_rows = dy (row stride ld_drows; either may be NULL; reduce
+ * them with vita_colsum_f32 when mul/add are vectors). */
 int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul,
-                                    int32_t M, int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, float* dmul_rows,
-                                    float* dadd_rows, vita_stream_t stream);
+                                    int32_t M, int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, int32_t dx_accumulate,
+                                    float* dmul_rows, float* dadd_rows, int64_t ld_drows, vita_stream_t stream);
 /* out[n] (+)= sum_m x[m,n] — bias gradients and broadcast-parameter gradients; deterministic.
  * partials: caller scratch of vita_colsum_partials_count(N) floats. */
 int64_t vita_colsum_partials_count(int32_t N);
@@ -241,10 +247,80 @@ int vita_sumsq_f32(const float* x, int64_t n, float* partials, float* out, vita_
 /* One fused pass over flat fp32 buffers: g *= grad_scale * min(1, max_norm/(sqrt(*gnorm_sq)*grad_scale + 1e-6))
  * (clip_grad_norm_, policy_trainer.py:83-87; gnorm_sq NULL or max_norm <= 0 = no clipping), AdamW
  * (vita_policy.py:222-229; `step` is 1-based), then ema -= (1-ema_decay)*(ema - p) when ema != NULL
- * (diffusers EMAModel.step, base_policy.py:45-49; policy_trainer.py:90-94). */
+ * (diffusers EMAModel.step, base_policy.py:45-49; policy_trainer.py:90-94).  Hyper-parameters are doubles: torch
+ * forms 1-beta, 1-lr*wd, lr/bias_correction in python floats and rounds to fp32 once. */
 int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq, float max_norm,
-                            float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                            float ema_decay, vita_stream_t stream);
+                            float grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
+                            double ema_decay, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Training forward + backward of the whole hot path in one call.
+ * --------------------------------------------------------------------------------------- */
+enum { VITA_ENC_CNN = 0, VITA_ENC_SIMPLE = 1 };
+
+typedef struct vita_encoder_weights {
+    int32_t kind; /* VITA_ENC_CNN: CNNActionEncoder (action_ae.py:282-327); VITA_ENC_SIMPLE: SimpleActionEncoder (:111-170) */
+    int32_t A;    /* action_dim */
+    int32_t T;    /* pred_horizon */
+    int32_t C;    /* cnn: enc_hidden_dim (conv channels); simple: action_latent_dim = D / T */
+    int32_t NL;   /* num_layers <= VITA_MAX_LAYERS; cnn needs T >> NL >= 1 (action_ae.py:311) */
+    int32_t D;    /* latent_dim */
+    /* cnn:    w1[i] = action_encoder.encoder.{2i}.weight (C, Cin, 5), b1[i] its bias; w2/b2 unused
+     * simple: w1[i]/b1[i] = layers.i.fc1 (4C, C), w2[i]/b2[i] = layers.i.fc2 (C, 4C) */
+    const float *w1[VITA_MAX_LAYERS], *b1[VITA_MAX_LAYERS];
+    const float *w2[VITA_MAX_LAYERS], *b2[VITA_MAX_LAYERS];
+    /* cnn: latent_proj (D, C*(T>>NL));  simple: input_proj (C, A) */
+    const float *proj_w, *proj_b;
+} vita_encoder_weights;
+
+typedef struct vita_policy_weights {
+    int32_t O;                      /* observer feature dim */
+    const float *obs_w, *obs_b;     /* obs_encoder (D, O), vita_policy.py:77 */
+    vita_flownet_weights flow;
+    vita_encoder_weights enc;
+    vita_decoder_weights dec;
+} vita_policy_weights;
+
+typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 */
+    int32_t num_steps;            /* flow_matcher.num_sampling_steps */
+    int32_t recon_l1;             /* 1: recon_loss_type l1 (default), 0: l2 */
+    int32_t decode_flow_latents;  /* vita_policy.py:153 */
+    float consistency_weight;     /* FLC, :162-165 */
+    float enc_recon_weight;       /* AE,  :183-187 */
+    float flow_recon_weight;      /* FLD, :174-178 */
+} vita_loss_config;
+
+enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,
+       VITA_LOSS_COUNT = 8 };
+
+/* vita_compute_loss_f32 — VitaPolicy.compute_loss from observer features on (vita_policy.py:112-189, defaults: plain
+ * autoencoder, nothing frozen, contrastive weights 0) followed by its backward pass (loss.backward(),
+ * policy_trainer.py:82), every kernel enqueued by this one call:
+ *   z0 = obs_encoder(obs); z1 = action_encoder(actions);
+ *   L_flow = mean((flow_net(xt, t) - ut)^2), (xt, ut) = CFM(z0[pair_i], z1[pair_j], t)       flow_matchers.py:30-36
+ *   pred = Euler_K(z0);  L_c = mse(pred, z1);  L_fr = recon(dec(pred), actions);  L_er = recon(dec(z1), actions)
+ *   loss = L_flow + cw*L_c + fw*L_fr + ew*L_er
+ * `t` (B) and the OT pairing (NULL = identity) are inputs: the reference draws them on the host (torchcfm / POT).
+ * losses: device float[VITA_LOSS_COUNT], indexed by VITA_LOSS_*.
+ * grads: NULL = forward only; else a descriptor of the same shape whose pointers are the gradient buffers: each
+ *   is OVERWRITTEN with d loss / d weight (no zero_grad needed).  The K sampler steps and the flow-matching
+ *   evaluation share one weight-gradient GEMM per layer (their rows are stacked in the workspace).
+ * d_obs_features: NULL or (B,O) receiving d loss / d obs_features — what flows on into a trainable observer
+ *   (the ResNet backbone is in the reference's single AdamW group, vita_policy.py:222-229).
+ * grad_ready: NULL or 3 hipEvent_t recorded on `stream` when (0) the decoder's, (1) the flow net's, (2) every
+ *   gradient is final — the points at which a data-parallel caller starts that bucket's all-reduce. */
+size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B);
+int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
+                          const float* obs_features, int64_t ldobs, const float* actions, const float* t,
+                          const int64_t* pair_i, const int64_t* pair_j, int32_t B, float* losses,
+                          float* d_obs_features, int64_t ld_dobs,
+                          void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream);
+
+/* vita_action_encoder_forward_f32 — CNNActionEncoder.forward / SimpleActionEncoder.forward alone:
+ * actions (B,T,A) contiguous -> latents (B,D). */
+size_t vita_action_encoder_workspace_bytes(const vita_encoder_weights* w, int32_t B);
+int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* actions, float* latents, int64_t ldl, int32_t B,
+                                    void* workspace, size_t workspace_bytes, vita_stream_t stream);
 
 #ifdef __cplusplus
 }

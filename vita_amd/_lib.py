@@ -33,6 +33,7 @@ class LinearArgs(C.Structure):
         ("resid", c_fp), ("ld_resid", C.c_int64),
         ("preact", c_fp), ("ld_preact", C.c_int64),
         ("a_col", C.c_int32), ("b_col", C.c_int32),
+        ("act_grad_z", c_fp), ("ld_act_grad_z", C.c_int64),
     ]
 
 
@@ -63,6 +64,35 @@ class DecoderWeights(C.Structure):
     ]
 
 
+class EncoderWeights(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("A", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("NL", C.c_int32), ("D", C.c_int32),
+        ("w1", _PA), ("b1", _PA), ("w2", _PA), ("b2", _PA),
+        ("proj_w", c_fp), ("proj_b", c_fp),
+    ]
+
+
+class PolicyWeights(C.Structure):
+    _fields_ = [
+        ("O", C.c_int32),
+        ("obs_w", c_fp), ("obs_b", c_fp),
+        ("flow", FlowNetWeights),
+        ("enc", EncoderWeights),
+        ("dec", DecoderWeights),
+    ]
+
+
+class LossConfig(C.Structure):
+    _fields_ = [
+        ("num_steps", C.c_int32), ("recon_l1", C.c_int32), ("decode_flow_latents", C.c_int32),
+        ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
+    ]
+
+
+ENC_CNN, ENC_SIMPLE = 0, 1
+LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss")
+LOSS_COUNT = 8
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
 SIGNATURES = {
     "vita_abi_version": (C.c_int, []),
@@ -84,24 +114,31 @@ SIGNATURES = {
                                             c_fp, C.c_size_t, c_fp]),
     "vita_loss_partials_count": (C.c_int32, []),
     "vita_mse_loss_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
-    "vita_mse_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
+    "vita_mse_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, C.c_int32, c_fp]),
     "vita_l1_loss_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
-    "vita_l1_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
+    "vita_l1_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, C.c_int32, c_fp]),
     "vita_cfm_interpolate_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
-    "vita_cfm_interpolate_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_cfm_interpolate_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_act_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
     "vita_act_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
-    "vita_gate_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int64, C.c_float, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_gate_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, C.c_int64, C.c_float, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp]),
     "vita_layernorm_modulate_bwd_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32,
-                                                  C.c_float, C.c_int32, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
+                                                  C.c_float, C.c_int32, c_fp, C.c_int64, C.c_int32, c_fp, c_fp, C.c_int64, c_fp]),
+    "vita_compute_loss_workspace_bytes": (C.c_size_t, [C.POINTER(PolicyWeights), C.POINTER(LossConfig), C.c_int32]),
+    "vita_compute_loss_f32": (C.c_int, [C.POINTER(PolicyWeights), C.POINTER(PolicyWeights), C.POINTER(LossConfig), c_fp, C.c_int64,
+                                        c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp, C.c_int64, C.POINTER(c_fp), c_fp,
+                                        C.c_size_t, c_fp]),
+    "vita_action_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderWeights), C.c_int32]),
+    "vita_action_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderWeights), c_fp, c_fp, C.c_int64, C.c_int32, c_fp, C.c_size_t,
+                                                  c_fp]),
     "vita_colsum_partials_count": (C.c_int64, [C.c_int32]),
     "vita_colsum_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int32, c_fp]),
     "vita_im2col_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_col2im_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_nlc_ncl_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_sumsq_f32": (C.c_int, [c_fp, C.c_int64, c_fp, c_fp, c_fp]),
-    "vita_adamw_ema_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, c_fp, C.c_float, C.c_float, C.c_float,
-                                          C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, c_fp]),
+    "vita_adamw_ema_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, c_fp, C.c_float, C.c_float, C.c_double,
+                                          C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

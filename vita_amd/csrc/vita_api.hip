@@ -5,7 +5,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 
-#include "vita_common.h"
+#include "vita_host.h"
 
 namespace vita {
 
@@ -17,24 +17,6 @@ void set_error(const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
 }
-
-int gemm_f32(const vita_linear_args& a, hipStream_t stream);
-int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
-int launch_step_times(float* ts, int K, hipStream_t s);
-int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
-                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s);
-
-// ---- workspace carving -------------------------------------------------------------------
-struct Carver {
-    char* base;
-    size_t off = 0;
-    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
-    float* take(size_t nfloats) {
-        float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
-        off += (nfloats * sizeof(float) + 255) & ~size_t(255);
-        return r;
-    }
-};
 
 struct FlowWs {
     float *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
@@ -57,7 +39,7 @@ static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, 
     return f;
 }
 
-static int check_flow_weights(const vita_flownet_weights* w, const char* who) {
+int check_flow_weights(const vita_flownet_weights* w, const char* who) {
     VITA_REQUIRE(w != nullptr, "%s: null weights", who);
     VITA_REQUIRE(w->D > 0 && w->H > 0 && w->FF > 0 && w->TE >= 4 && w->TE % 2 == 0,
                  "%s: bad dims D=%d H=%d FF=%d TE=%d", who, w->D, w->H, w->FF, w->TE);
@@ -70,20 +52,6 @@ static int check_flow_weights(const vita_flownet_weights* w, const char* who) {
                      "%s: null weight pointer in layer %d", who, l);
     return VITA_OK;
 }
-
-static vita_linear_args lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* b, float* Y, int64_t ldy, int M,
-                            int N, int K, int act) {
-    vita_linear_args a{};
-    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = b; a.Y = Y; a.ldy = ldy;
-    a.M = M; a.N = N; a.K = K; a.act = act;
-    return a;
-}
-
-#define VITA_TRY(expr)              \
-    do {                            \
-        int rc__ = (expr);          \
-        if (rc__ != VITA_OK) return rc__; \
-    } while (0)
 
 // Time path for T timesteps already in f.ts: sinusoid -> Linear+Mish -> Linear (+SiLU, the only
 // form the modulators consume) -> per-layer modulator Linear into f.mod (T, L, 3H).
@@ -139,19 +107,6 @@ static int flow_eval(const vita_flownet_weights* w, const FlowWs& f, const float
     return VITA_OK;
 }
 
-static int check_ws(const void* ws, size_t have, size_t need, const char* who) {
-    if (need == 0) return VITA_OK;
-    if (ws == nullptr || have < need) {
-        set_error("%s: workspace too small or null (have %zu bytes, need %zu)", who, have, need);
-        return VITA_ERR_WORKSPACE;
-    }
-    if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) {
-        set_error("%s: workspace must be 256-byte aligned", who);
-        return VITA_ERR_WORKSPACE;
-    }
-    return VITA_OK;
-}
-
 static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
                       float* traj, void* ws, hipStream_t s) {
     const int D = w->D, H = w->H, L = w->L;
@@ -185,7 +140,7 @@ static DecWs carve_dec(void* ws, const vita_decoder_weights* w, int B) {
     d.bytes = c.off;
     return d;
 }
-static int check_dec_weights(const vita_decoder_weights* w, const char* who) {
+int check_dec_weights(const vita_decoder_weights* w, const char* who) {
     VITA_REQUIRE(w != nullptr, "%s: null decoder weights", who);
     VITA_REQUIRE(w->D > 0 && w->HD > 0 && w->OUT > 0 && w->NL >= 0 && w->NL <= VITA_MAX_LAYERS, "%s: bad decoder dims", who);
     VITA_REQUIRE(w->in_w && w->in_b && w->out_w && w->out_b, "%s: null decoder weight pointer", who);

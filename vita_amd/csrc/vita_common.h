@@ -73,6 +73,39 @@ __device__ __forceinline__ float apply_act_t(float x) {
     else return x;
 }
 
+// ---- activation derivatives (autograd of the activations above; torch's *Backward formulas) ----
+__device__ __forceinline__ float act_grad(float z, int act) {
+    switch (act) {
+        case VITA_ACT_RELU: return z > 0.f ? 1.f : 0.f;
+        case VITA_ACT_GELU_ERF: {   // torch GeluBackward (none): cdf + z*pdf
+            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
+            const float pdf = expf(-0.5f * z * z) * 0.3989422804014327f;
+            return cdf + z * pdf;
+        }
+        case VITA_ACT_GELU_TANH: {  // torch GeluBackward (tanh)
+            const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
+            const float z2 = z * z;
+            const float inner = kBeta * (z + kKappa * z2 * z);
+            const float th = tanhf(inner);
+            const float left = 0.5f * z, right = 1.0f + th;
+            const float dth = 1.0f - th * th;
+            const float dinner = kBeta * (1.0f + 3.0f * kKappa * z2);
+            return 0.5f * right + left * (dth * dinner);
+        }
+        case VITA_ACT_SILU: {
+            const float s = 1.0f / (1.0f + expf(-z));
+            return s * (1.0f + z * (1.0f - s));
+        }
+        case VITA_ACT_MISH: {       // d/dz z*tanh(softplus(z)) = tanh(sp) + z*sigmoid(z)*(1-tanh(sp)^2)
+            const float sp = z > 20.0f ? z : log1pf(expf(z));
+            const float th = tanhf(sp);
+            const float s = 1.0f / (1.0f + expf(-z));
+            return th + z * s * (1.0f - th * th);
+        }
+        default: return 1.f;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(EW_THREADS) void finalize_mean_kernel(const float* 
 template <bool L1>
 __global__ __launch_bounds__(EW_THREADS) void diff_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                             const float* __restrict__ gout, float* __restrict__ ga,
-                                                            float* __restrict__ gb) {
+                                                            float* __restrict__ gb, int accumulate) {
     const float g = gout[0];
     const float inv_n = 1.0f / (float)n;
     const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
@@ -91,8 +91,8 @@ __global__ __launch_bounds__(EW_THREADS) void diff_bwd_kernel(const float* __res
         float v;
         if (L1) v = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * inv_n * g;   // sign(d)/n * gout
         else v = (2.0f * d) * inv_n * g;                                    // 2 d / n * gout
-        if (ga) ga[i] = v;
-        if (gb) gb[i] = -v;
+        if (ga) ga[i] = accumulate ? ga[i] + v : v;
+        if (gb) gb[i] = accumulate ? gb[i] - v : -v;
     }
 }
 
@@ -108,12 +108,12 @@ static int loss_fwd(const float* a, const float* b, int64_t n, float* partials, 
     return VITA_OK;
 }
 template <bool L1>
-static int loss_bwd(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, hipStream_t s,
+static int loss_bwd(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, int accumulate, hipStream_t s,
                     const char* name) {
     VITA_REQUIRE(a && b && gout, "%s: null pointer", name);
     VITA_REQUIRE(n > 0, "%s: n must be > 0", name);
     if (!ga && !gb) return VITA_OK;
-    hipLaunchKernelGGL((diff_bwd_kernel<L1>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, n, gout, ga, gb);
+    hipLaunchKernelGGL((diff_bwd_kernel<L1>), dim3(ew_grid(n)), dim3(EW_THREADS), 0, s, a, b, n, gout, ga, gb, accumulate);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
@@ -277,11 +277,13 @@ int vita_mse_loss_fwd_f32(const float* a, const float* b, int64_t n, float* part
 int vita_l1_loss_fwd_f32(const float* a, const float* b, int64_t n, float* partials, float* out, vita_stream_t stream) {
     return loss_fwd<true>(a, b, n, partials, out, (hipStream_t)stream, "vita_l1_loss_fwd_f32");
 }
-int vita_mse_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, vita_stream_t stream) {
-    return loss_bwd<false>(a, b, n, gout, ga, gb, (hipStream_t)stream, "vita_mse_loss_bwd_f32");
+int vita_mse_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, int32_t accumulate,
+                          vita_stream_t stream) {
+    return loss_bwd<false>(a, b, n, gout, ga, gb, accumulate, (hipStream_t)stream, "vita_mse_loss_bwd_f32");
 }
-int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, vita_stream_t stream) {
-    return loss_bwd<true>(a, b, n, gout, ga, gb, (hipStream_t)stream, "vita_l1_loss_bwd_f32");
+int vita_l1_loss_bwd_f32(const float* a, const float* b, int64_t n, const float* gout, float* ga, float* gb, int32_t accumulate,
+                         vita_stream_t stream) {
+    return loss_bwd<true>(a, b, n, gout, ga, gb, accumulate, (hipStream_t)stream, "vita_l1_loss_bwd_f32");
 }
 
 int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, const int64_t* pair_i, const int64_t* pair_j, float* xt,

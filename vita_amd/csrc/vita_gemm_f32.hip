@@ -342,9 +342,10 @@ bool gemm_f32_dma_eligible(const vita_linear_args& a);
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     if (a.M == 0 && a.N > 0 && a.K > 0) return VITA_OK;  // empty batch: nothing to do (pointers may be null)
     VITA_REQUIRE(a.X && a.W && a.Y, "vita_linear_f32: X, W and Y must be non-null");
+    if (a.a_col || a.b_col) return gemm_f32_t(a, stream);
     VITA_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "vita_linear_f32: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     VITA_REQUIRE(a.preact == nullptr || a.ld_preact >= a.N, "vita_linear_f32: ld_preact must be >= N");
-    if (a.a_col || a.b_col) return gemm_f32_t(a, stream);
+    VITA_REQUIRE(a.act_grad_z == nullptr, "vita_linear_f32: act_grad_z is a backward-pass (a_col/b_col) option");
     VITA_REQUIRE(a.ldx >= a.K && a.ldw >= a.K && a.ldy >= a.N,
                  "vita_linear_f32: leading dimension smaller than the row (ldx=%lld ldw=%lld ldy=%lld, K=%d N=%d)",
                  (long long)a.ldx, (long long)a.ldw, (long long)a.ldy, a.K, a.N);

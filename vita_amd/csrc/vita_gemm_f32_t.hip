@@ -1,6 +1,6 @@
 // fp32 MFMA GEMM with transposed ("column") operands — the backward passes of nn.Linear.
 //
-//   C[M,N] = resid + gate_scalar * ( sum_k A(m,k) * B(n,k) + bias )
+//   C[M,N] = resid + gate_scalar * act'(Z[M,N]) * ( sum_k A(m,k) * B(n,k) + bias )      (act' only when act_grad_z is given)
 //     a_col = 0 : A(m,k) = X[m*ldx + k]        a_col = 1 : A(m,k) = X[k*ldx + m]
 //     b_col = 0 : B(n,k) = W[n*ldw + k]        b_col = 1 : B(n,k) = W[k*ldw + n]
 //
@@ -26,6 +26,7 @@ struct GemmParamsT {
     int M, N, K;
     int use_gate_scalar; float gate_scalar;
     const float* resid; int64_t ld_resid;
+    const float* act_grad_z; int64_t ld_act_grad_z; int act;   // epilogue: *= act'(z[row,col])
     int tiles_m, tiles_n;
 };
 
@@ -197,6 +198,7 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
                 const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < p.M && col_ok) {
                     float v = acc[i][j][r] + bias;
+                    if (p.act_grad_z != nullptr) v = v * act_grad(p.act_grad_z[(int64_t)row * p.ld_act_grad_z + col], p.act);
                     if (p.use_gate_scalar) v = v * p.gate_scalar;
                     if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
                     p.Y[(int64_t)row * p.ldy + col] = v;
@@ -223,15 +225,24 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream) {
     VITA_REQUIRE(a.X && a.W && a.Y, "%s: X, W and Y must be non-null", who);
     VITA_REQUIRE(a.M > 0 && a.N > 0 && a.K >= 0, "%s: bad shape M=%d N=%d K=%d", who, a.M, a.N, a.K);
     VITA_REQUIRE(a.ldx >= (a.a_col ? a.M : a.K) && a.ldw >= (a.b_col ? a.N : a.K) && a.ldy >= a.N, "%s: leading dimension too small", who);
-    VITA_REQUIRE(a.pro == VITA_PRO_NONE && a.act == VITA_ACT_NONE && a.gate == nullptr && a.preact == nullptr,
-                 "%s: prologue / activation / vector gate / preact are not available with a_col or b_col", who);
+    VITA_REQUIRE(a.pro == VITA_PRO_NONE && a.gate == nullptr && a.preact == nullptr,
+                 "%s: prologue / vector gate / preact are not available with a_col or b_col", who);
+    VITA_REQUIRE(a.act >= VITA_ACT_NONE && a.act <= VITA_ACT_MISH, "%s: unknown activation %d", who, a.act);
+    VITA_REQUIRE(a.act == VITA_ACT_NONE || a.act_grad_z != nullptr, "%s: with a_col/b_col `act` names the derivative applied from act_grad_z, which is null", who);
+    VITA_REQUIRE(a.act_grad_z == nullptr || a.ld_act_grad_z >= a.N, "%s: ld_act_grad_z must be >= N", who);
     VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "%s: ld_resid must be >= N", who);
     VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W, "%s: Y must not alias X or W", who);
+    if (a.K == 0 && a.resid == nullptr) {   // empty reduction: the result is the bias (wgrad of an empty batch is zero)
+        VITA_REQUIRE(a.bias == nullptr, "%s: K == 0 with a bias is not supported", who);
+        VITA_CHECK_HIP(hipMemset2DAsync(a.Y, (size_t)a.ldy * 4, 0, (size_t)a.N * 4, (size_t)a.M, stream));
+        return VITA_OK;
+    }
     GemmParamsT p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias; p.Y = a.Y; p.ldy = a.ldy;
     p.M = a.M; p.N = a.N; p.K = a.K;
     p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
     p.resid = a.resid; p.ld_resid = a.ld_resid;
+    p.act_grad_z = a.act_grad_z; p.ld_act_grad_z = a.ld_act_grad_z; p.act = a.act;
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool vx = al(a.X) && a.ldx % 4 == 0 && (a.a_col ? a.M % 4 == 0 : a.K % 4 == 0);
     const bool vw = al(a.W) && a.ldw % 4 == 0 && (a.b_col ? a.N % 4 == 0 : a.K % 4 == 0);

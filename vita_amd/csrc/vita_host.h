@@ -1,0 +1,73 @@
+// Host-side helpers shared by the C-ABI orchestrators (vita_api.hip, vita_loss_step.hip):
+// workspace carving, vita_linear_args builders, early-return macro and the internal launchers.
+#pragma once
+#include "vita_common.h"
+
+namespace vita {
+
+int gemm_f32(const vita_linear_args& a, hipStream_t stream);
+int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
+int launch_step_times(float* ts, int K, hipStream_t s);
+int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
+                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s);
+int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st);
+int launch_weighted_sum(const float* vals, const float* host_w, int n, float* out, hipStream_t st);
+
+// Bump allocator over the caller's workspace; with base == nullptr it only measures.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(void* p) : base(static_cast<char*>(p)) {}
+    float* take(size_t nfloats) {
+        float* r = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += (nfloats * sizeof(float) + 255) & ~size_t(255);
+        return r;
+    }
+};
+
+inline vita_linear_args lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* b, float* Y, int64_t ldy, int M,
+                            int N, int K, int act) {
+    vita_linear_args a{};
+    a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = b; a.Y = Y; a.ldy = ldy;
+    a.M = M; a.N = N; a.K = K; a.act = act;
+    return a;
+}
+// dX[M, in] = dY[M, out] . W[out, in]  (autograd of F.linear w.r.t. its input)
+inline vita_linear_args dgrad(const float* dY, int64_t ld_dy, const float* W, int64_t ldw, float* dX, int64_t ld_dx, int M, int in_f,
+                              int out_f) {
+    vita_linear_args a = lin(dY, ld_dy, W, ldw, nullptr, dX, ld_dx, M, in_f, out_f, VITA_ACT_NONE);
+    a.b_col = 1;
+    return a;
+}
+// dW[out, in] = dY[R, out]^T . X[R, in]  (w.r.t. its weight), R = rows stacked over every use of W
+inline vita_linear_args wgrad(const float* dY, int64_t ld_dy, const float* X, int64_t ldx, float* dW, int64_t ld_dw, int R, int in_f,
+                              int out_f) {
+    vita_linear_args a = lin(dY, ld_dy, X, ldx, nullptr, dW, ld_dw, out_f, in_f, R, VITA_ACT_NONE);
+    a.a_col = 1;
+    a.b_col = 1;
+    return a;
+}
+
+#define VITA_TRY(expr)                    \
+    do {                                  \
+        int rc__ = (expr);                \
+        if (rc__ != VITA_OK) return rc__; \
+    } while (0)
+
+inline int check_ws(const void* ws, size_t have, size_t need, const char* who) {
+    if (need == 0) return VITA_OK;
+    if (ws == nullptr || have < need) {
+        set_error("%s: workspace too small or null (have %zu bytes, need %zu)", who, have, need);
+        return VITA_ERR_WORKSPACE;
+    }
+    if ((reinterpret_cast<uintptr_t>(ws) & 255u) != 0) {
+        set_error("%s: workspace must be 256-byte aligned", who);
+        return VITA_ERR_WORKSPACE;
+    }
+    return VITA_OK;
+}
+
+int check_flow_weights(const vita_flownet_weights* w, const char* who);
+int check_dec_weights(const vita_decoder_weights* w, const char* who);
+
+}  // namespace vita

@@ -1,0 +1,650 @@
+// vita_compute_loss_f32 — the training forward + backward of the VITA hot path, orchestrated on
+// the host side of the C ABI: VitaPolicy.compute_loss (vita_policy.py:112-189) and the autograd
+// pass loss.backward() runs over it (policy_trainer.py:82).
+//
+// Design (MI355X-first, not a tape): the graph is static, so the backward is written out by hand
+// and every buffer it needs is carved from the caller's workspace.
+//   * The flow net is evaluated E = 1 + K times per step (one flow-matching evaluation with a
+//     per-row t, K Euler steps with a per-step t).  Activations of all E evaluations are saved
+//     STACKED, [layer][eval][B rows], so that after the E input-gradient chains have run, every
+//     weight gets ONE wgrad GEMM over E*B rows (dW = sum_e dY_e^T X_e = [dY_0;..]^T [X_0;..]) and one
+//     column-sum for its bias: 7x fewer wgrad launches and 7x less dW read-modify-write traffic than
+//     accumulating per evaluation.
+//   * dU / dY2 overwrite the saved pre-activations in place (the dgrad GEMM's epilogue multiplies by
+//     act'(z) reading the element it then overwrites), so the backward adds no (B, FF) buffers.
+//   * Both decoder calls (dec(pred), dec(z1)) run as one 2B-row batch.
+//   * Modulation rows: the time path is evaluated once for B + K timesteps; per-row (gamma, scale,
+//     shift) gradients of the flow-matching evaluation land directly in the time path's gradient
+//     table, those of Euler step k are column-summed into row B + k.
+//   * Gradients are written, not accumulated: each weight's gradient is produced by exactly one GEMM.
+#include "vita_host.h"
+
+namespace vita {
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// Generic "input_proj -> NL x timm Mlp(exact GELU) -> [output_proj]" stack: SimpleActionDecoder
+// (action_ae.py:226-279) and SimpleActionEncoder (:111-170, per-timestep rows).
+// ------------------------------------------------------------------------------------------------
+struct Stack {
+    int IN = 0, TR = 0, FF = 0, NL = 0, OUT = 0;  // OUT == 0: no output projection
+    const float *in_w = nullptr, *in_b = nullptr;
+    const float *fc1_w[VITA_MAX_LAYERS] = {}, *fc1_b[VITA_MAX_LAYERS] = {};
+    const float *fc2_w[VITA_MAX_LAYERS] = {}, *fc2_b[VITA_MAX_LAYERS] = {};
+    const float *out_w = nullptr, *out_b = nullptr;
+};
+struct StackWs {
+    float *A = nullptr;    // (NL+1, M, TR) trunk activations
+    float *P = nullptr;    // (NL, M, FF) fc1 pre-activations, overwritten by their gradients
+    float *G = nullptr;    // (NL, M, FF) gelu(P)
+    float *out = nullptr;  // (M, OUT)
+    float *dOut = nullptr; // (M, OUT)
+    float *s1 = nullptr, *s2 = nullptr;  // (M, TR) gradient ping-pong
+};
+Stack stack_of(const vita_decoder_weights& w) {
+    Stack s;
+    s.IN = w.D; s.TR = w.HD; s.FF = w.HD; s.NL = w.NL; s.OUT = w.OUT;
+    s.in_w = w.in_w; s.in_b = w.in_b; s.out_w = w.out_w; s.out_b = w.out_b;
+    for (int i = 0; i < w.NL; ++i) { s.fc1_w[i] = w.fc1_w[i]; s.fc1_b[i] = w.fc1_b[i]; s.fc2_w[i] = w.fc2_w[i]; s.fc2_b[i] = w.fc2_b[i]; }
+    return s;
+}
+Stack stack_of_simple_encoder(const vita_encoder_weights& w) {
+    Stack s;
+    s.IN = w.A; s.TR = w.C; s.FF = 4 * w.C; s.NL = w.NL; s.OUT = 0;
+    s.in_w = w.proj_w; s.in_b = w.proj_b;
+    for (int i = 0; i < w.NL; ++i) { s.fc1_w[i] = w.w1[i]; s.fc1_b[i] = w.b1[i]; s.fc2_w[i] = w.w2[i]; s.fc2_b[i] = w.b2[i]; }
+    return s;
+}
+StackWs carve_stack(Carver& c, const Stack& s, size_t M, bool train) {
+    StackWs w;
+    w.A = c.take((size_t)(s.NL + 1) * M * s.TR);
+    w.P = c.take((size_t)s.NL * M * s.FF);
+    w.G = c.take((size_t)s.NL * M * s.FF);
+    if (s.OUT) w.out = c.take(M * s.OUT);
+    if (train) {
+        if (s.OUT) w.dOut = c.take(M * s.OUT);
+        w.s1 = c.take(M * s.TR);
+        w.s2 = c.take(M * s.TR);
+    }
+    return w;
+}
+// last_trunk: when non-null the final trunk activation A[NL] is written there instead (contiguous (M, TR))
+int stack_fwd(const Stack& s, const StackWs& w, const float* x, int64_t ldx, int M, float* last_trunk, hipStream_t st) {
+    const size_t tr = (size_t)M * s.TR, ff = (size_t)M * s.FF;
+    auto trunk = [&](int i) { return (i == s.NL && last_trunk) ? last_trunk : w.A + (size_t)i * tr; };
+    VITA_TRY(gemm_f32(lin(x, ldx, s.in_w, s.IN, s.in_b, trunk(0), s.TR, M, s.TR, s.IN, VITA_ACT_NONE), st));
+    for (int i = 0; i < s.NL; ++i) {
+        vita_linear_args a = lin(trunk(i), s.TR, s.fc1_w[i], s.TR, s.fc1_b[i], w.G + i * ff, s.FF, M, s.FF, s.TR, VITA_ACT_GELU_ERF);
+        a.preact = w.P + i * ff; a.ld_preact = s.FF;
+        VITA_TRY(gemm_f32(a, st));
+        VITA_TRY(gemm_f32(lin(w.G + i * ff, s.FF, s.fc2_w[i], s.FF, s.fc2_b[i], trunk(i + 1), s.TR, M, s.TR, s.FF, VITA_ACT_NONE), st));
+    }
+    if (s.OUT) VITA_TRY(gemm_f32(lin(trunk(s.NL), s.TR, s.out_w, s.TR, s.out_b, w.out, s.OUT, M, s.OUT, s.TR, VITA_ACT_NONE), st));
+    return VITA_OK;
+}
+inline float* mut(const float* p) { return const_cast<float*>(p); }
+
+// d_top: gradient of the stack's result — (M, OUT) w.dOut when OUT > 0, else the gradient of A[NL] (M, TR).
+// g: gradient buffers in the same descriptor.  dx: NULL or (M, IN) receiving the input gradient.
+int stack_bwd(const Stack& s, const Stack& g, const StackWs& w, const float* x, int64_t ldx, int M, const float* last_trunk,
+              const float* d_top, int64_t ld_top, float* dx, int64_t ld_dx, float* cs_part, hipStream_t st) {
+    const size_t tr = (size_t)M * s.TR, ff = (size_t)M * s.FF;
+    auto trunk = [&](int i) -> const float* { return (i == s.NL && last_trunk) ? last_trunk : w.A + (size_t)i * tr; };
+    const float* dA = d_top;
+    int64_t ld_dA = ld_top;
+    float* free_buf = w.s1;
+    float* other = w.s2;
+    if (s.OUT) {
+        VITA_TRY(gemm_f32(wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT), st));
+        VITA_TRY(vita_colsum_f32(d_top, ld_top, M, s.OUT, cs_part, mut(g.out_b), 0, st));
+        VITA_TRY(gemm_f32(dgrad(d_top, ld_top, s.out_w, s.TR, free_buf, s.TR, M, s.TR, s.OUT), st));
+        dA = free_buf; ld_dA = s.TR;
+        float* tmp = free_buf; free_buf = other; other = tmp;
+    }
+    for (int i = s.NL - 1; i >= 0; --i) {
+        float* P = w.P + i * ff;
+        VITA_TRY(gemm_f32(wgrad(dA, ld_dA, w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
+        VITA_TRY(vita_colsum_f32(dA, ld_dA, M, s.TR, cs_part, mut(g.fc2_b[i]), 0, st));
+        vita_linear_args a = dgrad(dA, ld_dA, s.fc2_w[i], s.FF, P, s.FF, M, s.FF, s.TR);   // dP = (dA . W2) * gelu'(P), in place
+        a.act = VITA_ACT_GELU_ERF; a.act_grad_z = P; a.ld_act_grad_z = s.FF;
+        VITA_TRY(gemm_f32(a, st));
+        VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
+        VITA_TRY(vita_colsum_f32(P, s.FF, M, s.FF, cs_part, mut(g.fc1_b[i]), 0, st));
+        VITA_TRY(gemm_f32(dgrad(P, s.FF, s.fc1_w[i], s.TR, free_buf, s.TR, M, s.TR, s.FF), st));
+        dA = free_buf; ld_dA = s.TR;
+        float* tmp = free_buf; free_buf = other; other = tmp;
+    }
+    VITA_TRY(gemm_f32(wgrad(dA, ld_dA, x, ldx, mut(g.in_w), s.IN, M, s.IN, s.TR), st));
+    VITA_TRY(vita_colsum_f32(dA, ld_dA, M, s.TR, cs_part, mut(g.in_b), 0, st));
+    if (dx) VITA_TRY(gemm_f32(dgrad(dA, ld_dA, s.in_w, s.IN, dx, ld_dx, M, s.IN, s.TR), st));
+    return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CNNActionEncoder (action_ae.py:282-327) on channels-last rows: Conv1d(k5,s2,p2) = im2col + GEMM.
+// ------------------------------------------------------------------------------------------------
+struct CnnWs {
+    float *col[VITA_MAX_LAYERS] = {};  // (B*Lout_i, Cin_i*5)
+    float *out[VITA_MAX_LAYERS] = {};  // (B*Lout_i, C) post-ReLU, channels-last
+    float *flat = nullptr;             // (B, C*Lf) in (C, L) order when Lf > 1
+    float *d0 = nullptr, *d1 = nullptr; // gradient ping-pong, each max(B*Lout_0*C, B*C*Lf, B*L_i*C_i)
+};
+inline int conv_len(int T, int i) { return T >> i; }  // requires T % 2^NL == 0
+CnnWs carve_cnn(Carver& c, const vita_encoder_weights& w, size_t B, bool train) {
+    CnnWs s;
+    size_t dmax = 0;
+    for (int i = 0; i < w.NL; ++i) {
+        const size_t cin = i == 0 ? w.A : w.C, lout = conv_len(w.T, i + 1);
+        s.col[i] = c.take(B * lout * cin * 5);
+        s.out[i] = c.take(B * lout * w.C);
+        dmax = dmax > B * lout * w.C ? dmax : B * lout * w.C;
+        dmax = dmax > B * conv_len(w.T, i) * cin ? dmax : B * conv_len(w.T, i) * cin;
+    }
+    const size_t lf = conv_len(w.T, w.NL);
+    if (lf > 1) s.flat = c.take(B * w.C * lf);
+    dmax = dmax > B * w.C * lf ? dmax : B * w.C * lf;
+    if (train) { s.d0 = c.take(dmax); s.d1 = c.take(dmax); }
+    return s;
+}
+int cnn_fwd(const vita_encoder_weights& w, const CnnWs& s, const float* actions, float* z, int64_t ldz, int B, hipStream_t st) {
+    const float* x = actions;
+    for (int i = 0; i < w.NL; ++i) {
+        const int cin = i == 0 ? w.A : w.C, lin_ = conv_len(w.T, i), lout = conv_len(w.T, i + 1);
+        VITA_TRY(vita_im2col_k5s2_f32(x, s.col[i], B, lin_, cin, st));
+        VITA_TRY(gemm_f32(lin(s.col[i], cin * 5, w.w1[i], cin * 5, w.b1[i], s.out[i], w.C, B * lout, w.C, cin * 5, VITA_ACT_RELU), st));
+        x = s.out[i];
+    }
+    const int lf = conv_len(w.T, w.NL);
+    const float* flat = w.NL ? s.out[w.NL - 1] : actions;
+    const int cf = w.NL ? w.C : w.A;
+    if (lf > 1) {
+        VITA_TRY(vita_nlc_ncl_f32(flat, s.flat, B, lf, cf, 1, st));   // x.view(B,-1) of the (B,C,L) tensor, :323
+        flat = s.flat;
+    }
+    return gemm_f32(lin(flat, cf * lf, w.proj_w, cf * lf, w.proj_b, z, ldz, B, w.D, cf * lf, VITA_ACT_NONE), st);
+}
+int cnn_bwd(const vita_encoder_weights& w, const vita_encoder_weights& g, const CnnWs& s, const float* actions, const float* dz,
+            int64_t ld_dz, int B, float* cs_part, hipStream_t st) {
+    const int lf = conv_len(w.T, w.NL);
+    const int cf = w.NL ? w.C : w.A;
+    const float* flat = lf > 1 ? s.flat : (w.NL ? s.out[w.NL - 1] : actions);
+    VITA_TRY(gemm_f32(wgrad(dz, ld_dz, flat, cf * lf, mut(g.proj_w), cf * lf, B, cf * lf, w.D), st));
+    VITA_TRY(vita_colsum_f32(dz, ld_dz, B, w.D, cs_part, mut(g.proj_b), 0, st));
+    if (w.NL == 0) return VITA_OK;
+    float* d_out = s.d0;
+    float* d_alt = s.d1;
+    VITA_TRY(gemm_f32(dgrad(dz, ld_dz, w.proj_w, cf * lf, d_out, cf * lf, B, cf * lf, w.D), st));
+    if (lf > 1) {
+        VITA_TRY(vita_nlc_ncl_f32(d_out, d_alt, B, lf, cf, 0, st));
+        float* t = d_out; d_out = d_alt; d_alt = t;
+    }
+    for (int i = w.NL - 1; i >= 0; --i) {
+        const int cin = i == 0 ? w.A : w.C, lin_ = conv_len(w.T, i), lout = conv_len(w.T, i + 1);
+        const int rows = B * lout;
+        // ReLU backward from the saved output (out > 0 <=> pre-activation > 0)
+        VITA_TRY(vita_act_bwd_f32(s.out[i], d_out, d_alt, (int64_t)rows * w.C, VITA_ACT_RELU, st));
+        VITA_TRY(gemm_f32(wgrad(d_alt, w.C, s.col[i], cin * 5, mut(g.w1[i]), cin * 5, rows, cin * 5, w.C), st));
+        VITA_TRY(vita_colsum_f32(d_alt, w.C, rows, w.C, cs_part, mut(g.b1[i]), 0, st));
+        if (i > 0) {
+            VITA_TRY(gemm_f32(dgrad(d_alt, w.C, w.w1[i], cin * 5, s.col[i], cin * 5, rows, cin * 5, w.C), st));  // dcol reuses col
+            VITA_TRY(vita_col2im_k5s2_f32(s.col[i], d_out, B, lin_, cin, st));
+        }
+    }
+    return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// SimpleFlowNet with saved activations
+// ------------------------------------------------------------------------------------------------
+struct FlowTrainWs {
+    // time path over T = B + K rows (flow-matching rows first, then one row per Euler step)
+    float *ts, *sin, *hidpre, *hid, *tepre, *silu, *mod, *dmod, *dsilu, *dte, *dhid;
+    // evaluations e = 0 (flow matching), 1..K (Euler step e-1)
+    float *X, *Hs, *HN, *U, *G, *Y2, *DV, *DH0, *DHNF, *RN;
+    float *dhn, *DM;
+};
+FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B, size_t K, bool train) {
+    FlowTrainWs f{};
+    const size_t T = B + K, E = 1 + K, H = w.H, FF = w.FF, D = w.D, L = w.L, TE = w.TE;
+    f.ts = c.take(T);
+    f.sin = c.take(T * TE);
+    f.hidpre = c.take(T * 4 * TE);
+    f.hid = c.take(T * 4 * TE);
+    f.tepre = c.take(T * H);
+    f.silu = c.take(T * H);
+    f.mod = c.take(T * L * 3 * H);
+    f.X = c.take(E * B * D);
+    f.Hs = c.take((L + 1) * E * B * H);
+    f.HN = c.take((L + 1) * E * B * H);
+    f.U = c.take(L * E * B * FF);
+    f.G = c.take(L * E * B * FF);
+    f.Y2 = c.take(L * E * B * H);
+    if (train) {
+        f.dmod = c.take(T * L * 3 * H);
+        f.dsilu = c.take(T * H);
+        f.dte = c.take(T * H);
+        f.dhid = c.take(T * 4 * TE);
+        f.DV = c.take(E * B * D);
+        f.DH0 = c.take(E * B * H);
+        f.DHNF = c.take(E * B * H);
+        f.RN = c.take(E * B * H);
+        f.dhn = c.take(B * H);
+        f.DM = c.take(B * L * 3 * H);
+    }
+    return f;
+}
+
+struct FlowCtx {
+    const vita_flownet_weights* w;
+    FlowTrainWs f;
+    int B, K, E;
+    hipStream_t st;
+    size_t bh() const { return (size_t)B * w->H; }
+    size_t bf() const { return (size_t)B * w->FF; }
+    float* Hs(int l, int e) const { return f.Hs + ((size_t)l * E + e) * bh(); }
+    float* HN(int l, int e) const { return f.HN + ((size_t)l * E + e) * bh(); }
+    float* U(int l, int e) const { return f.U + ((size_t)l * E + e) * bf(); }
+    float* G(int l, int e) const { return f.G + ((size_t)l * E + e) * bf(); }
+    float* Y2(int l, int e) const { return f.Y2 + ((size_t)l * E + e) * bh(); }
+    float* X(int e) const { return f.X + (size_t)e * B * w->D; }
+    float* DV(int e) const { return f.DV + (size_t)e * B * w->D; }
+    float* DH0(int e) const { return f.DH0 + (size_t)e * bh(); }
+    float* DHNF(int e) const { return f.DHNF + (size_t)e * bh(); }
+    float* RN(int e) const { return f.RN + (size_t)e * bh(); }
+};
+
+// simple_flow_net.py:66-71,27-30 for the T rows of f.ts, keeping the pre-activations
+int time_path_fwd(const FlowCtx& c, int T) {
+    const vita_flownet_weights* w = c.w;
+    const int TE = w->TE, H = w->H, L = w->L;
+    VITA_TRY(launch_sinusoid(c.f.ts, c.f.sin, TE, T, TE, c.st));
+    vita_linear_args a = lin(c.f.sin, TE, w->te1_w, TE, w->te1_b, c.f.hid, 4 * TE, T, 4 * TE, TE, VITA_ACT_MISH);
+    a.preact = c.f.hidpre; a.ld_preact = 4 * TE;
+    VITA_TRY(gemm_f32(a, c.st));
+    vita_linear_args b = lin(c.f.hid, 4 * TE, w->te3_w, 4 * TE, w->te3_b, c.f.silu, H, T, H, 4 * TE, VITA_ACT_SILU);
+    b.preact = c.f.tepre; b.ld_preact = H;
+    VITA_TRY(gemm_f32(b, c.st));
+    for (int l = 0; l < L; ++l)
+        VITA_TRY(gemm_f32(lin(c.f.silu, H, w->mod_w[l], H, w->mod_b[l], c.f.mod + (size_t)l * 3 * H, (int64_t)L * 3 * H, T, 3 * H, H,
+                              VITA_ACT_NONE), c.st));
+    return VITA_OK;
+}
+
+int time_path_bwd(const FlowCtx& c, const vita_flownet_weights& g, int T, float* cs_part) {
+    const vita_flownet_weights* w = c.w;
+    const int TE = w->TE, H = w->H, L = w->L;
+    const int64_t ldm = (int64_t)L * 3 * H;
+    if (L == 0) {  // the time embedding feeds only the modulators: without layers its gradient is zero
+        VITA_CHECK_HIP(hipMemsetAsync(mut(g.te1_w), 0, (size_t)4 * TE * TE * 4, c.st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(g.te1_b), 0, (size_t)4 * TE * 4, c.st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(g.te3_w), 0, (size_t)H * 4 * TE * 4, c.st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(g.te3_b), 0, (size_t)H * 4, c.st));
+        return VITA_OK;
+    }
+    for (int l = 0; l < L; ++l) {
+        const float* dm = c.f.dmod + (size_t)l * 3 * H;
+        vita_linear_args a = dgrad(dm, ldm, w->mod_w[l], H, c.f.dsilu, H, T, H, 3 * H);
+        if (l > 0) { a.resid = c.f.dsilu; a.ld_resid = H; }
+        VITA_TRY(gemm_f32(a, c.st));
+        VITA_TRY(gemm_f32(wgrad(dm, ldm, c.f.silu, H, mut(g.mod_w[l]), H, T, H, 3 * H), c.st));
+        VITA_TRY(vita_colsum_f32(dm, ldm, T, 3 * H, cs_part, mut(g.mod_b[l]), 0, c.st));
+    }
+    VITA_TRY(vita_act_bwd_f32(c.f.tepre, c.f.dsilu, c.f.dte, (int64_t)T * H, VITA_ACT_SILU, c.st));
+    VITA_TRY(gemm_f32(wgrad(c.f.dte, H, c.f.hid, 4 * TE, mut(g.te3_w), 4 * TE, T, 4 * TE, H), c.st));
+    VITA_TRY(vita_colsum_f32(c.f.dte, H, T, H, cs_part, mut(g.te3_b), 0, c.st));
+    vita_linear_args a = dgrad(c.f.dte, H, w->te3_w, 4 * TE, c.f.dhid, 4 * TE, T, 4 * TE, H);
+    a.act = VITA_ACT_MISH; a.act_grad_z = c.f.hidpre; a.ld_act_grad_z = 4 * TE;
+    VITA_TRY(gemm_f32(a, c.st));
+    VITA_TRY(gemm_f32(wgrad(c.f.dhid, 4 * TE, c.f.sin, TE, mut(g.te1_w), TE, T, TE, 4 * TE), c.st));
+    VITA_TRY(vita_colsum_f32(c.f.dhid, 4 * TE, T, 4 * TE, cs_part, mut(g.te1_b), 0, c.st));
+    return VITA_OK;
+}
+
+// SimpleFlowNet.forward (simple_flow_net.py:99-108) for evaluation e, saving what the backward needs.
+// Y = resid + dt * v when resid != NULL (flow_matchers.py:71), else Y = v.
+int flow_eval_fwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, float* Y, int64_t ldy, const float* resid,
+                  int64_t ld_resid, float dt) {
+    const vita_flownet_weights* w = c.w;
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = c.B;
+    VITA_TRY(gemm_f32(lin(c.X(e), D, w->in_w, D, w->in_b, c.Hs(0, e), H, B, H, D, VITA_ACT_NONE), c.st));
+    for (int l = 0; l < L; ++l) {
+        const float* gamma = mod + (size_t)l * 3 * H;
+        const float* scale = gamma + H;
+        const float* shift = gamma + 2 * H;
+        VITA_TRY(launch_ln_mod(c.Hs(l, e), H, c.HN(l, e), H, B, H, 1e-6f, VITA_PRO_LN_MOD, scale, ld_mod, shift, ld_mod, c.st));
+        vita_linear_args a = lin(c.HN(l, e), H, w->fc1_w[l], H, w->fc1_b[l], c.G(l, e), FF, B, FF, H, VITA_ACT_GELU_TANH);
+        a.preact = c.U(l, e); a.ld_preact = FF;
+        VITA_TRY(gemm_f32(a, c.st));
+        vita_linear_args b = lin(c.G(l, e), FF, w->fc2_w[l], FF, w->fc2_b[l], c.Hs(l + 1, e), H, B, H, FF, VITA_ACT_NONE);
+        b.preact = c.Y2(l, e); b.ld_preact = H;
+        b.gate = gamma; b.ld_gate = ld_mod; b.resid = c.Hs(l, e); b.ld_resid = H;
+        VITA_TRY(gemm_f32(b, c.st));
+    }
+    VITA_TRY(launch_ln_mod(c.Hs(L, e), H, c.HN(L, e), H, B, H, 1e-5f, VITA_PRO_LN_AFFINE, w->norm_w, 0, w->norm_b, 0, c.st));
+    vita_linear_args o = lin(c.HN(L, e), H, w->out_w, H, w->out_b, Y, ldy, B, D, H, VITA_ACT_NONE);
+    if (resid) { o.use_gate_scalar = 1; o.gate_scalar = dt; o.resid = resid; o.ld_resid = ld_resid; }
+    return gemm_f32(o, c.st);
+}
+
+// Input-gradient chain of evaluation e from DV(e) = d loss / d v.  Leaves dU in U(l,e), dY2 in Y2(l,e), dH0 in DH0(e),
+// dHNF / RN for the final norm, the modulation-row gradients in dm_rows (B, L*3H), and
+//   dx = resid + DH0 . W_in      (resid: the identity branch of the Euler update, or NULL)
+int flow_eval_bwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, float* dm_rows, float* dx, int64_t ld_dx,
+                  const float* resid, int64_t ld_resid) {
+    const vita_flownet_weights* w = c.w;
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = c.B;
+    const int64_t ldm = (int64_t)L * 3 * H;
+    VITA_TRY(gemm_f32(dgrad(c.DV(e), D, w->out_w, H, c.DHNF(e), H, B, H, D), c.st));
+    VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(L, e), H, c.DHNF(e), H, w->norm_w, 0, B, H, 1e-5f, VITA_PRO_LN_AFFINE, c.DH0(e), H, 0,
+                                             c.RN(e), nullptr, H, c.st));
+    for (int l = L - 1; l >= 0; --l) {
+        const float* gamma = mod + (size_t)l * 3 * H;
+        const float* scale = gamma + H;
+        float* dmr = dm_rows + (size_t)l * 3 * H;
+        // x_{l+1} = x_l + y2 * gamma
+        VITA_TRY(vita_gate_bwd_f32(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st));
+        vita_linear_args a = dgrad(c.Y2(l, e), H, w->fc2_w[l], FF, c.U(l, e), FF, B, FF, H);   // dU = (dY2 . W2) * gelu_tanh'(U)
+        a.act = VITA_ACT_GELU_TANH; a.act_grad_z = c.U(l, e); a.ld_act_grad_z = FF;
+        VITA_TRY(gemm_f32(a, c.st));
+        VITA_TRY(gemm_f32(dgrad(c.U(l, e), FF, w->fc1_w[l], H, c.f.dhn, H, B, H, FF), c.st));
+        VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(l, e), H, c.f.dhn, H, scale, ld_mod, B, H, 1e-6f, VITA_PRO_LN_MOD, c.DH0(e), H, 1,
+                                                 dmr + H, dmr + 2 * H, ldm, c.st));
+    }
+    vita_linear_args a = dgrad(c.DH0(e), H, w->in_w, D, dx, ld_dx, B, D, H);
+    if (resid) { a.resid = resid; a.ld_resid = ld_resid; }
+    return gemm_f32(a, c.st);
+}
+
+// One wgrad GEMM + one column-sum per weight over the E*B stacked rows.
+int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs_part) {
+    const vita_flownet_weights* w = c.w;
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, R = c.E * c.B;
+    VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
+    VITA_TRY(vita_colsum_f32(c.f.DV, D, R, D, cs_part, mut(g.out_b), 0, c.st));
+    VITA_TRY(vita_colsum_f32(c.f.RN, H, R, H, cs_part, mut(g.norm_w), 0, c.st));
+    VITA_TRY(vita_colsum_f32(c.f.DHNF, H, R, H, cs_part, mut(g.norm_b), 0, c.st));
+    for (int l = 0; l < L; ++l) {
+        VITA_TRY(gemm_f32(wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
+        VITA_TRY(vita_colsum_f32(c.Y2(l, 0), H, R, H, cs_part, mut(g.fc2_b[l]), 0, c.st));
+        VITA_TRY(gemm_f32(wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
+        VITA_TRY(vita_colsum_f32(c.U(l, 0), FF, R, FF, cs_part, mut(g.fc1_b[l]), 0, c.st));
+    }
+    VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
+    VITA_TRY(vita_colsum_f32(c.f.DH0, H, R, H, cs_part, mut(g.in_b), 0, c.st));
+    return VITA_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// whole-step workspace
+// ------------------------------------------------------------------------------------------------
+struct StepWs {
+    float *consts, *loss_part, *cs_part;
+    float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
+    float *ut, *vt, *dut, *dxt, *dxa, *dxb;
+    FlowTrainWs flow;
+    StackWs dec;
+    StackWs senc;   // simple encoder
+    CnnWs cnn;
+    size_t bytes;
+};
+
+int max_colsum_n(const vita_policy_weights& w) {
+    int n = w.flow.L * 3 * w.flow.H;
+    auto up = [&](int v) { if (v > n) n = v; };
+    up(w.flow.FF); up(w.flow.H); up(w.flow.D); up(4 * w.flow.TE);
+    up(w.dec.HD); up(w.dec.OUT); up(w.dec.D);
+    up(w.enc.C * 4); up(w.enc.D);
+    return n;
+}
+
+StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config& cfg, size_t B, bool train) {
+    Carver c(ws);
+    StepWs s{};
+    const size_t D = w.flow.D;
+    const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0;
+    s.consts = c.take(16);
+    s.loss_part = c.take((size_t)vita_loss_partials_count());
+    s.cs_part = c.take((size_t)vita_colsum_partials_count(max_colsum_n(w)));
+    s.z0 = c.take(B * D);
+    s.ZZ = c.take(2 * B * D);
+    s.ut = c.take(B * D);
+    s.vt = c.take(B * D);
+    if (train) {
+        s.dz0 = c.take(B * D);
+        s.dZZ = c.take(2 * B * D);
+        s.dut = c.take(B * D);
+        s.dxt = c.take(B * D);
+        s.dxa = c.take(B * D);
+        s.dxb = c.take(B * D);
+    }
+    s.flow = carve_flow_train(c, w.flow, B, K, train);
+    s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
+    if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
+    else s.cnn = carve_cnn(c, w.enc, B, train);
+    s.bytes = c.off;
+    return s;
+}
+
+int check_enc_weights(const vita_encoder_weights* w, const char* who) {
+    VITA_REQUIRE(w->kind == VITA_ENC_CNN || w->kind == VITA_ENC_SIMPLE, "%s: unknown encoder kind %d", who, w->kind);
+    VITA_REQUIRE(w->A > 0 && w->T > 0 && w->C > 0 && w->D > 0 && w->NL >= 0 && w->NL <= VITA_MAX_LAYERS, "%s: bad encoder dims", who);
+    VITA_REQUIRE(w->proj_w && w->proj_b, "%s: null encoder projection", who);
+    if (w->kind == VITA_ENC_CNN) {
+        VITA_REQUIRE((w->T >> w->NL) >= 1 && (w->T % (1 << w->NL)) == 0,
+                     "%s: cnn encoder needs pred_horizon %% 2^num_layers == 0 (T=%d, NL=%d; action_ae.py:311)", who, w->T, w->NL);
+        for (int i = 0; i < w->NL; ++i) VITA_REQUIRE(w->w1[i] && w->b1[i], "%s: null conv weight %d", who, i);
+    } else {
+        VITA_REQUIRE(w->C * w->T == w->D, "%s: simple encoder needs action_latent_dim * pred_horizon == latent_dim", who);
+        for (int i = 0; i < w->NL; ++i) VITA_REQUIRE(w->w1[i] && w->b1[i] && w->w2[i] && w->b2[i], "%s: null encoder weight %d", who, i);
+    }
+    return VITA_OK;
+}
+
+int check_policy(const vita_policy_weights* w, const char* who) {
+    VITA_REQUIRE(w != nullptr, "%s: null weights", who);
+    VITA_REQUIRE(w->O > 0 && w->obs_w && w->obs_b, "%s: bad obs_encoder", who);
+    VITA_TRY(check_flow_weights(&w->flow, who));
+    VITA_TRY(check_dec_weights(&w->dec, who));
+    VITA_TRY(check_enc_weights(&w->enc, who));
+    VITA_REQUIRE(w->flow.D == w->dec.D && w->flow.D == w->enc.D, "%s: latent dims differ (flow %d, decoder %d, encoder %d)", who, w->flow.D,
+                 w->dec.D, w->enc.D);
+    VITA_REQUIRE(w->dec.OUT == w->enc.T * w->enc.A, "%s: decoder OUT=%d != T*A=%d", who, w->dec.OUT, w->enc.T * w->enc.A);
+    VITA_REQUIRE(w->flow.H <= 2048, "%s: training supports hidden_dim <= 2048 (got %d)", who, w->flow.H);
+    return VITA_OK;
+}
+
+int encoder_fwd(const vita_encoder_weights& w, const StepWs& s, const float* actions, float* z1, int64_t ldz, int B, hipStream_t st) {
+    if (w.kind == VITA_ENC_SIMPLE) {
+        VITA_REQUIRE(ldz == w.D, "simple encoder output must be contiguous");
+        return stack_fwd(stack_of_simple_encoder(w), s.senc, actions, w.A, B * w.T, z1, st);
+    }
+    return cnn_fwd(w, s.cnn, actions, z1, ldz, B, st);
+}
+
+}  // namespace
+
+}  // namespace vita
+
+using namespace vita;
+
+extern "C" {
+
+size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B) {
+    if (!w || !cfg || B <= 0) return 0;
+    return carve_step(nullptr, *w, *cfg, (size_t)B, true).bytes;
+}
+
+int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
+                          const float* obs_features, int64_t ldobs, const float* actions, const float* t, const int64_t* pair_i,
+                          const int64_t* pair_j, int32_t B, float* losses, float* d_obs_features, int64_t ld_dobs,
+                          void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream) {
+    const char* who = "vita_compute_loss_f32";
+    VITA_TRY(check_policy(w, who));
+    if (grads) VITA_TRY(check_policy(grads, "vita_compute_loss_f32 (grads)"));
+    VITA_REQUIRE(cfg != nullptr, "%s: null config", who);
+    VITA_REQUIRE(!cfg->decode_flow_latents || cfg->num_steps >= 1, "%s: num_steps must be >= 1 (got %d)", who, cfg->num_steps);
+    VITA_REQUIRE(cfg->consistency_weight >= 0.f && cfg->enc_recon_weight >= 0.f && cfg->flow_recon_weight >= 0.f, "%s: negative loss weight", who);
+    VITA_REQUIRE(B >= 1, "%s: B must be >= 1 (the mean over an empty batch is undefined)", who);
+    VITA_REQUIRE(obs_features && actions && t && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/losses", who);
+    VITA_REQUIRE(d_obs_features == nullptr || (grads != nullptr && ld_dobs >= w->O), "%s: d_obs_features needs grads and ld_dobs >= O", who);
+    if (grads) {
+        VITA_REQUIRE(grads->O == w->O && grads->flow.D == w->flow.D && grads->flow.H == w->flow.H && grads->flow.FF == w->flow.FF &&
+                         grads->flow.L == w->flow.L && grads->flow.TE == w->flow.TE && grads->dec.HD == w->dec.HD &&
+                         grads->dec.NL == w->dec.NL && grads->dec.OUT == w->dec.OUT && grads->enc.kind == w->enc.kind &&
+                         grads->enc.C == w->enc.C && grads->enc.NL == w->enc.NL && grads->enc.A == w->enc.A && grads->enc.T == w->enc.T,
+                     "%s: the gradient descriptor's dims differ from the weights'", who);
+    }
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_compute_loss_workspace_bytes(w, cfg, B), who));
+    hipStream_t st = (hipStream_t)stream;
+    const bool train = grads != nullptr;
+    StepWs s = carve_step(workspace, *w, *cfg, (size_t)B, true);
+    const int D = w->flow.D, H = w->flow.H, L = w->flow.L, OUT = w->dec.OUT;
+    const bool do_sample = cfg->decode_flow_latents != 0;
+    const int K = do_sample ? cfg->num_steps : 0;
+    const int T = B + K;
+    const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
+    const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
+    const bool dec_enc = cfg->enc_recon_weight > 0.f;
+    const int64_t ldm = (int64_t)L * 3 * H;
+    float* pred = s.ZZ;
+    float* z1 = s.ZZ + (size_t)B * D;
+    FlowCtx fc{&w->flow, s.flow, B, K, 1 + K, st};
+
+    // loss weights as device scalars (seeds of the backward pass) ; zero the outputs
+    const float seeds[4] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight};
+    VITA_TRY(launch_set_scalars(s.consts, seeds, 4, st));
+    VITA_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * VITA_LOSS_COUNT, st));
+
+    // ---- forward ------------------------------------------------------------------------------
+    VITA_TRY(gemm_f32(lin(obs_features, ldobs, w->obs_w, w->O, w->obs_b, s.z0, D, B, D, w->O, VITA_ACT_NONE), st));   // :114
+    VITA_TRY(encoder_fwd(w->enc, s, actions, z1, D, B, st));                                                          // :123
+    // time path for the B per-row timesteps of the flow-matching draw and the K Euler steps
+    VITA_CHECK_HIP(hipMemcpyAsync(s.flow.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
+    if (K > 0) VITA_TRY(launch_step_times(s.flow.ts + B, K, st));
+    VITA_TRY(time_path_fwd(fc, T));
+    // flow-matching loss, flow_matchers.py:30-36
+    VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
+    VITA_TRY(flow_eval_fwd(fc, 0, s.flow.mod, ldm, s.vt, D, nullptr, 0, 0.f));
+    VITA_TRY(vita_mse_loss_fwd_f32(s.vt, s.ut, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_FLOW, st));
+    // Euler sampler with grad, vita_policy.py:153-160 / flow_matchers.py:55-79
+    const float dt = K > 0 ? (float)(1.0 / (double)K) : 0.f;
+    if (do_sample) {
+        VITA_CHECK_HIP(hipMemcpyAsync(fc.X(1), s.z0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+        for (int k = 0; k < K; ++k) {
+            const int e = k + 1;
+            float* dst = (k == K - 1) ? pred : fc.X(e + 1);
+            VITA_TRY(flow_eval_fwd(fc, e, s.flow.mod + (size_t)(B + k) * ldm, 0, dst, D, fc.X(e), D, dt));
+        }
+        if (do_cons) VITA_TRY(vita_mse_loss_fwd_f32(pred, z1, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_CONSISTENCY, st));   // :162-165
+    }
+    // both decoder calls as one batch of rows [r0, r0 + M) of ZZ = [pred; z1]      :174-187
+    const Stack dec = stack_of(w->dec);
+    const int r0 = dec_pred ? 0 : B;
+    const int M = (dec_pred ? B : 0) + (dec_enc ? B : 0);
+    const int enc_row = dec_pred ? B : 0;   // row of the decoder batch where dec(z1) starts
+    const int64_t n_rec = (int64_t)B * OUT;
+    if (M > 0) {
+        VITA_TRY(stack_fwd(dec, s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, st));
+        auto recon = cfg->recon_l1 ? vita_l1_loss_fwd_f32 : vita_mse_loss_fwd_f32;
+        if (dec_pred) VITA_TRY(recon(s.dec.out, actions, n_rec, s.loss_part, losses + VITA_LOSS_FLOW_RECON, st));
+        if (dec_enc) VITA_TRY(recon(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.loss_part, losses + VITA_LOSS_ENC_RECON, st));
+    }
+    const float wsum[5] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
+                           dec_enc ? cfg->enc_recon_weight : 0.f};
+    VITA_TRY(launch_weighted_sum(losses, wsum, 5, losses + VITA_LOSS_TOTAL, st));
+    if (!train) return VITA_OK;
+
+    // ---- backward -----------------------------------------------------------------------------
+    const vita_policy_weights& g = *grads;
+    auto record = [&](int i) -> int {
+        if (grad_ready && grad_ready[i]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)grad_ready[i], st));
+        return VITA_OK;
+    };
+    // decoder: dZZ = d loss / d [pred; z1] through the reconstruction terms
+    if (!dec_pred) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ, 0, (size_t)B * D * 4, st));
+    if (!dec_enc) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ + (size_t)B * D, 0, (size_t)B * D * 4, st));
+    if (M > 0) {
+        auto recon_bwd = cfg->recon_l1 ? vita_l1_loss_bwd_f32 : vita_mse_loss_bwd_f32;
+        if (dec_pred) VITA_TRY(recon_bwd(s.dec.out, actions, n_rec, s.consts + 2, s.dec.dOut, nullptr, 0, st));
+        if (dec_enc)
+            VITA_TRY(recon_bwd(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.consts + 3, s.dec.dOut + (size_t)enc_row * OUT, nullptr, 0, st));
+        VITA_TRY(stack_bwd(dec, stack_of(g.dec), s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, s.dec.dOut, OUT, s.dZZ + (size_t)r0 * D, D,
+                           s.cs_part, st));
+    } else {  // the decoder takes no part in the loss
+        const Stack gd = stack_of(g.dec);
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.in_w), 0, (size_t)gd.TR * gd.IN * 4, st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.in_b), 0, (size_t)gd.TR * 4, st));
+        for (int i = 0; i < gd.NL; ++i) {
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc1_w[i]), 0, (size_t)gd.FF * gd.TR * 4, st));
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc1_b[i]), 0, (size_t)gd.FF * 4, st));
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc2_w[i]), 0, (size_t)gd.TR * gd.FF * 4, st));
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc2_b[i]), 0, (size_t)gd.TR * 4, st));
+        }
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_w), 0, (size_t)gd.OUT * gd.TR * 4, st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_b), 0, (size_t)gd.OUT * 4, st));
+    }
+    VITA_TRY(record(0));
+    float* dpred = s.dZZ;
+    float* dz1 = s.dZZ + (size_t)B * D;
+    if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
+    // flow-matching evaluation
+    VITA_TRY(vita_mse_loss_bwd_f32(s.vt, s.ut, (int64_t)B * D, s.consts + 0, fc.DV(0), s.dut, 0, st));
+    VITA_TRY(flow_eval_bwd(fc, 0, s.flow.mod, ldm, s.flow.dmod, s.dxt, D, nullptr, 0));
+    // Euler steps, last to first: dx_k = dx_{k+1} + J_k^T (dt * dx_{k+1})
+    if (do_sample) {
+        const float* dxn = dpred;
+        for (int k = K - 1; k >= 0; --k) {
+            const int e = k + 1;
+            VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, dt, fc.DV(e), nullptr, 0, B, D, st));
+            float* dst = (k == 0) ? s.dz0 : ((k & 1) ? s.dxa : s.dxb);
+            VITA_TRY(flow_eval_bwd(fc, e, s.flow.mod + (size_t)(B + k) * ldm, 0, s.flow.DM, dst, D, dxn, D));
+            if (L > 0) VITA_TRY(vita_colsum_f32(s.flow.DM, ldm, B, L * 3 * H, s.cs_part, s.flow.dmod + (size_t)(B + k) * ldm, 0, st));
+            dxn = dst;
+        }
+    } else {
+        VITA_CHECK_HIP(hipMemsetAsync(s.dz0, 0, (size_t)B * D * 4, st));
+    }
+    VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
+    VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
+    VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
+    VITA_TRY(record(1));
+    // encoders
+    if (w->enc.kind == VITA_ENC_SIMPLE) {
+        VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
+                           w->enc.C, nullptr, 0, s.cs_part, st));
+    } else {
+        VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, dz1, D, B, s.cs_part, st));
+    }
+    VITA_TRY(gemm_f32(wgrad(s.dz0, D, obs_features, ldobs, mut(g.obs_w), w->O, B, w->O, D), st));
+    VITA_TRY(vita_colsum_f32(s.dz0, D, B, D, s.cs_part, mut(g.obs_b), 0, st));
+    if (d_obs_features) VITA_TRY(gemm_f32(dgrad(s.dz0, D, w->obs_w, w->O, d_obs_features, ld_dobs, B, w->O, D), st));
+    VITA_TRY(record(2));
+    return VITA_OK;
+}
+
+size_t vita_action_encoder_workspace_bytes(const vita_encoder_weights* w, int32_t B) {
+    if (!w || B <= 0) return 0;
+    Carver c(nullptr);
+    if (w->kind == VITA_ENC_SIMPLE) carve_stack(c, stack_of_simple_encoder(*w), (size_t)B * w->T, false);
+    else carve_cnn(c, *w, (size_t)B, false);
+    return c.off;
+}
+
+int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* actions, float* latents, int64_t ldl, int32_t B,
+                                    void* workspace, size_t workspace_bytes, vita_stream_t stream) {
+    const char* who = "vita_action_encoder_forward_f32";
+    VITA_REQUIRE(w != nullptr, "%s: null weights", who);
+    VITA_TRY(check_enc_weights(w, who));
+    VITA_REQUIRE(B >= 0, "%s: B < 0", who);
+    if (B == 0) return VITA_OK;
+    VITA_REQUIRE(actions && latents && ldl >= w->D, "%s: bad actions/latents", who);
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_action_encoder_workspace_bytes(w, B), who));
+    Carver c(workspace);
+    StepWs s{};
+    if (w->kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(*w), (size_t)B * w->T, false);
+    else s.cnn = carve_cnn(c, *w, (size_t)B, false);
+    return encoder_fwd(*w, s, actions, latents, ldl, B, (hipStream_t)stream);
+}
+
+}  // extern "C"

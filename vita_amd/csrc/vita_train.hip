@@ -12,40 +12,6 @@ static inline int tgrid(int64_t items, int cap = 4096) {
     return (int)(b < 1 ? 1 : (b > cap ? cap : b));
 }
 
-// ---- activation derivative --------------------------------------------------------------------
-__device__ __forceinline__ float act_grad(float z, int act) {
-    switch (act) {
-        case VITA_ACT_RELU: return z > 0.f ? 1.f : 0.f;
-        case VITA_ACT_GELU_ERF: {   // torch GeluBackward (none): cdf + z*pdf
-            const float cdf = 0.5f * (1.0f + erff(z * 0.70710678118654752440f));
-            const float pdf = expf(-0.5f * z * z) * 0.3989422804014327f;
-            return cdf + z * pdf;
-        }
-        case VITA_ACT_GELU_TANH: {  // torch GeluBackward (tanh)
-            const float kBeta = 0.7978845608028654f, kKappa = 0.044715f;
-            const float z2 = z * z;
-            const float inner = kBeta * (z + kKappa * z2 * z);
-            const float th = tanhf(inner);
-            const float left = 0.5f * z, right = 1.0f + th;
-            const float dleft = 0.5f;
-            const float dth = 1.0f - th * th;
-            const float dinner = kBeta * (1.0f + 3.0f * kKappa * z2);
-            return dleft * right + left * (dth * dinner);
-        }
-        case VITA_ACT_SILU: {
-            const float s = 1.0f / (1.0f + expf(-z));
-            return s * (1.0f + z * (1.0f - s));
-        }
-        case VITA_ACT_MISH: {       // d/dz z*tanh(softplus(z)) = tanh(sp) + z*sigmoid(z)*(1-tanh(sp)^2)
-            const float sp = z > 20.0f ? z : log1pf(expf(z));
-            const float th = tanhf(sp);
-            const float s = 1.0f / (1.0f + expf(-z));
-            return th + z * s * (1.0f - th * th);
-        }
-        default: return 1.f;
-    }
-}
-
 __global__ __launch_bounds__(TT) void act_bwd_kernel(const float* __restrict__ z, const float* __restrict__ dy, float* __restrict__ dz,
                                                     int64_t n, int act) {
     const int64_t stride = (int64_t)gridDim.x * TT;
@@ -58,15 +24,16 @@ __global__ __launch_bounds__(TT) void act_fwd_kernel(const float* __restrict__ z
 
 // ---- gate backward: y = r + z*g ------------------------------------------------------------------
 // dz = dy*g ; dg_rows = dy*z (optional).  g: vector (ld_g = 0), matrix (ld_g >= N) or scalar (g == NULL).
-__global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ z, const float* __restrict__ g,
-                                                     int64_t ld_g, float gs, float* __restrict__ dz, float* __restrict__ dg, int M, int N) {
+// dy, z, dz are contiguous (M,N); z and dz may be the same buffer (each element is read, then written, by one thread).
+__global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ dy, const float* z, const float* __restrict__ g,
+                                                     int64_t ld_g, float gs, float* dz, float* __restrict__ dg, int64_t ld_dg, int M, int N) {
     const int64_t n = (int64_t)M * N, stride = (int64_t)gridDim.x * TT;
     for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
         const int r = (int)(i / N), c = (int)(i - (int64_t)r * N);
         const float d = dy[i];
         const float gv = g ? g[(int64_t)r * ld_g + c] : gs;
+        if (dg) dg[(int64_t)r * ld_dg + c] = d * z[i];
         if (dz) dz[i] = d * gv;
-        if (dg) dg[i] = d * z[i];
     }
 }
 
@@ -74,7 +41,8 @@ __global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ 
 constexpr int LNB_MAXC = 8;
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t ldd,
                                                          const float* __restrict__ mul, int64_t ld_mul, int M, int H, float eps, int mod,
-                                                         float* __restrict__ dx, int64_t ld_dx, float* __restrict__ dmul, float* __restrict__ dadd) {
+                                                         float* __restrict__ dx, int64_t ld_dx, int dx_accumulate, float* __restrict__ dmul,
+                                                         float* __restrict__ dadd, int64_t ld_dma) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -116,8 +84,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
                 const float g = dr[k];
                 const float m = mod ? (mr[k] + 1.0f) : mr[k];
                 const float dn = g * m;
-                if (dmul) dmul[(int64_t)row * H + k] = g * nrm;
-                if (dadd) dadd[(int64_t)row * H + k] = g;
+                if (dmul) dmul[(int64_t)row * ld_dma + k] = g * nrm;
+                if (dadd) dadd[(int64_t)row * ld_dma + k] = g;
                 v[c * 4 + j] = nrm;
                 d[c * 4 + j] = dn;
                 s1 += dn;
@@ -135,7 +103,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int k = (c * 64 + lane) * 4 + j;
-                if (k < H) dx[(int64_t)row * ld_dx + k] = rstd * (d[c * 4 + j] - s1 - v[c * 4 + j] * s2);
+                if (k < H) {
+                    const float gx = rstd * (d[c * 4 + j] - s1 - v[c * 4 + j] * s2);
+                    float* o = dx + (int64_t)row * ld_dx + k;
+                    *o = dx_accumulate ? *o + gx : gx;
+                }
             }
     }
 }
@@ -214,14 +186,14 @@ __global__ __launch_bounds__(TT) void nlc_ncl_kernel(const float* __restrict__ i
 // xt = t*x1[j] + (1-t)*x0[i], ut = x1[j]-x0[i]  =>  dx0[i] += (1-t)*dxt - dut ; dx1[j] += t*dxt + dut
 __global__ __launch_bounds__(TT) void cfm_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ dut, const float* __restrict__ t,
                                                     const int64_t* __restrict__ pi, const int64_t* __restrict__ pj, float* __restrict__ dx0,
-                                                    float* __restrict__ dx1, int B, int D) {
+                                                    float* __restrict__ dx1, int B, int D, int accumulate) {
     const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * TT;
     for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
         const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
         const float a = dxt ? dxt[i] : 0.f, u = dut ? dut[i] : 0.f, tt = t[r];
         const float g0 = (1.0f - tt) * a - u, g1 = tt * a + u;
-        if (dx0) { if (pi) atomicAdd(&dx0[pi[r] * D + c], g0); else dx0[i] = g0; }
-        if (dx1) { if (pj) atomicAdd(&dx1[pj[r] * D + c], g1); else dx1[i] = g1; }
+        if (dx0) { if (pi) atomicAdd(&dx0[pi[r] * D + c], g0); else dx0[i] = accumulate ? dx0[i] + g0 : g0; }
+        if (dx1) { if (pj) atomicAdd(&dx1[pj[r] * D + c], g1); else dx1[i] = accumulate ? dx1[i] + g1 : g1; }
     }
 }
 
@@ -253,27 +225,53 @@ __global__ __launch_bounds__(TT) void sumsq_stage2(const float* __restrict__ par
 // (base_policy.py:45-49): ema -= (1-decay)*(ema - p).
 __global__ __launch_bounds__(TT) void adamw_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                       float* __restrict__ v, float* __restrict__ ema, int64_t n, const float* __restrict__ gnorm_sq,
-                                                      float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps, float wd,
-                                                      float bc1, float bc2_sqrt, float ema_decay) {
+                                                      float max_norm, float grad_scale, float decay_mul, float one_m_b1, float beta2,
+                                                      float one_m_b2, float eps, float step_size, float bc2_sqrt, float one_m_decay) {
     float coef = grad_scale;
     if (gnorm_sq != nullptr && max_norm > 0.f) {
         const float norm = sqrtf(gnorm_sq[0]) * grad_scale;
         const float c = max_norm / (norm + 1e-6f);
         coef = grad_scale * (c < 1.0f ? c : 1.0f);
     }
-    const float step_size = lr / bc1;
-    const float one_m_decay = 1.0f - ema_decay;
     const int64_t stride = (int64_t)gridDim.x * TT;
     for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
         const float gi = g[i] * coef;
-        float pi = p[i] * (1.0f - lr * wd);
-        const float mi = m[i] + (gi - m[i]) * (1.0f - beta1);           // lerp_(g, 1-beta1)
-        const float vi = v[i] * beta2 + (1.0f - beta2) * gi * gi;
+        float pi = p[i] * decay_mul;                                     // p.mul_(1 - lr*wd)
+        const float mi = m[i] + (gi - m[i]) * one_m_b1;                  // exp_avg.lerp_(g, 1-beta1)
+        const float vi = v[i] * beta2 + one_m_b2 * gi * gi;              // exp_avg_sq.mul_(b2).addcmul_(g, g, 1-b2)
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
-        pi = pi - step_size * (mi / denom);
+        pi = pi - step_size * (mi / denom);                              // p.addcdiv_(exp_avg, denom, -lr/bc1)
         p[i] = pi; m[i] = mi; v[i] = vi;
         if (ema) ema[i] = ema[i] - one_m_decay * (ema[i] - pi);
     }
+}
+
+// ---- up to 8 host scalars into device memory (loss weights seeding the backward pass) -----------------
+struct Scalars8 { float v[8]; };
+__global__ void set_scalars_kernel(float* __restrict__ out, Scalars8 s, int n) {
+    if ((int)threadIdx.x < n) out[threadIdx.x] = s.v[threadIdx.x];
+}
+int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st) {
+    Scalars8 s{};
+    for (int i = 0; i < n && i < 8; ++i) s.v[i] = host_vals[i];
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(64), 0, st, out, s, n);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+// out[0] = sum_i w[i] * vals[i]   (the composite loss, vita_policy.py:126-187)
+__global__ void weighted_sum_kernel(const float* __restrict__ vals, Scalars8 w, int n, float* __restrict__ out) {
+    if (threadIdx.x == 0) {
+        float s = 0.f;
+        for (int i = 0; i < n; ++i) s = s + w.v[i] * vals[i];
+        out[0] = s;
+    }
+}
+int launch_weighted_sum(const float* vals, const float* host_w, int n, float* out, hipStream_t st) {
+    Scalars8 s{};
+    for (int i = 0; i < n && i < 8; ++i) s.v[i] = host_w[i];
+    hipLaunchKernelGGL(weighted_sum_kernel, dim3(1), dim3(64), 0, st, vals, s, n, out);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
 }
 
 }  // namespace vita
@@ -297,25 +295,27 @@ int vita_act_bwd_f32(const float* z, const float* dy, float* dz, int64_t n, int3
     LAUNCH_OK();
 }
 int vita_gate_bwd_f32(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz, float* dgate_rows,
-                      int32_t M, int32_t N, vita_stream_t s) {
+                      int64_t ld_dgate, int32_t M, int32_t N, vita_stream_t s) {
     VITA_REQUIRE(dy && M >= 0 && N > 0, "vita_gate_bwd_f32: bad arguments");
-    VITA_REQUIRE(dgate_rows == nullptr || z != nullptr, "vita_gate_bwd_f32: dgate needs z");
+    VITA_REQUIRE(dgate_rows == nullptr || (z != nullptr && ld_dgate >= N), "vita_gate_bwd_f32: dgate needs z and ld_dgate >= N");
     VITA_REQUIRE(gate == nullptr || ld_gate == 0 || ld_gate >= N, "vita_gate_bwd_f32: ld_gate must be 0 or >= N");
+    VITA_REQUIRE(dz == nullptr || dz != dy, "vita_gate_bwd_f32: dz must not alias dy");
     if (M == 0 || (!dz && !dgate_rows)) return VITA_OK;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(tgrid((int64_t)M * N)), dim3(TT), 0, (hipStream_t)s, dy, z, gate, ld_gate, gate_scalar, dz,
-                       dgate_rows, M, N);
+                       dgate_rows, ld_dgate, M, N);
     LAUNCH_OK();
 }
 int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul, int32_t M,
-                                    int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, float* dmul_rows, float* dadd_rows,
-                                    vita_stream_t s) {
+                                    int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, int32_t dx_accumulate, float* dmul_rows,
+                                    float* dadd_rows, int64_t ld_drows, vita_stream_t s) {
     VITA_REQUIRE(x && dy && mul, "vita_layernorm_modulate_bwd_f32: null pointer");
     VITA_REQUIRE(M >= 0 && H > 0 && H <= 64 * 4 * LNB_MAXC, "vita_layernorm_modulate_bwd_f32: H=%d outside (0, %d]", H, 64 * 4 * LNB_MAXC);
     VITA_REQUIRE(ldx >= H && ld_dy >= H && (ld_mul == 0 || ld_mul >= H) && (dx == nullptr || ld_dx >= H), "vita_layernorm_modulate_bwd_f32: bad leading dimension");
     VITA_REQUIRE(mode == VITA_PRO_LN_MOD || mode == VITA_PRO_LN_AFFINE, "vita_layernorm_modulate_bwd_f32: bad mode");
+    VITA_REQUIRE((dmul_rows == nullptr && dadd_rows == nullptr) || ld_drows >= H, "vita_layernorm_modulate_bwd_f32: ld_drows must be >= H");
     if (M == 0) return VITA_OK;
     hipLaunchKernelGGL(ln_mod_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)s, x, ldx, dy, ld_dy, mul, ld_mul, M, H, eps,
-                       mode == VITA_PRO_LN_MOD ? 1 : 0, dx, ld_dx, dmul_rows, dadd_rows);
+                       mode == VITA_PRO_LN_MOD ? 1 : 0, dx, ld_dx, dx_accumulate, dmul_rows, dadd_rows, ld_drows);
     LAUNCH_OK();
 }
 int64_t vita_colsum_partials_count(int32_t N) { return (int64_t)CS_R * (N > 0 ? N : 0); }
@@ -346,13 +346,15 @@ int vita_nlc_ncl_f32(const float* in, float* out, int32_t B, int32_t L, int32_t 
     LAUNCH_OK();
 }
 int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float* t, const int64_t* pair_i, const int64_t* pair_j, float* dx0,
-                                 float* dx1, int32_t B, int32_t D, vita_stream_t s) {
+                                 float* dx1, int32_t B, int32_t D, int32_t accumulate, vita_stream_t s) {
     VITA_REQUIRE(t && (dxt || dut) && B >= 0 && D > 0, "vita_cfm_interpolate_bwd_f32: bad arguments");
     if (B == 0 || (!dx0 && !dx1)) return VITA_OK;
     hipStream_t st = (hipStream_t)s;
-    if (dx0 && pair_i) VITA_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)B * D * 4, st));
-    if (dx1 && pair_j) VITA_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)B * D * 4, st));
-    hipLaunchKernelGGL(cfm_bwd_kernel, dim3(tgrid((int64_t)B * D)), dim3(TT), 0, st, dxt, dut, t, pair_i, pair_j, dx0, dx1, B, D);
+    if (!accumulate) {
+        if (dx0 && pair_i) VITA_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)B * D * 4, st));
+        if (dx1 && pair_j) VITA_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)B * D * 4, st));
+    }
+    hipLaunchKernelGGL(cfm_bwd_kernel, dim3(tgrid((int64_t)B * D)), dim3(TT), 0, st, dxt, dut, t, pair_i, pair_j, dx0, dx1, B, D, accumulate);
     LAUNCH_OK();
 }
 int vita_sumsq_f32(const float* x, int64_t n, float* partials, float* out, vita_stream_t s) {
@@ -363,13 +365,15 @@ int vita_sumsq_f32(const float* x, int64_t n, float* partials, float* out, vita_
     LAUNCH_OK();
 }
 int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float* ema, int64_t n, const float* gnorm_sq, float max_norm,
-                            float grad_scale, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
-                            float ema_decay, vita_stream_t s) {
+                            float grad_scale, double lr, double beta1, double beta2, double eps, double weight_decay, int32_t step,
+                            double ema_decay, vita_stream_t s) {
     VITA_REQUIRE(p && g && m && v && n > 0 && step >= 1, "vita_adamw_ema_step_f32: bad arguments");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adamw_ema_kernel, dim3(tgrid(n)), dim3(TT), 0, (hipStream_t)s, p, g, m, v, ema, n, gnorm_sq, max_norm, grad_scale, lr,
-                       beta1, beta2, eps, weight_decay, (float)bc1, (float)sqrt(bc2), ema_decay);
+    // scalar hyper-parameter arithmetic in double, rounded to fp32 once, as torch does with python floats
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adamw_ema_kernel, dim3(tgrid(n)), dim3(TT), 0, (hipStream_t)s, p, g, m, v, ema, n, gnorm_sq, max_norm, grad_scale,
+                       (float)(1.0 - lr * weight_decay), (float)(1.0 - beta1), (float)beta2, (float)(1.0 - beta2), (float)eps,
+                       (float)(lr / bc1), (float)sqrt(bc2), (float)(1.0 - ema_decay));
     LAUNCH_OK();
 }
 

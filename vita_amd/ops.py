@@ -284,7 +284,7 @@ def _loss_bwd(fn_name: str, a: Tensor, b: Tensor, gout: Tensor, need_a=True, nee
     gb = torch.empty_like(b) if need_b else None
     L.check(getattr(lib, fn_name)(a.data_ptr(), b.data_ptr(), a.numel(), gout.data_ptr(),
                                   ga.data_ptr() if ga is not None else None,
-                                  gb.data_ptr() if gb is not None else None, _stream(a)), fn_name)
+                                  gb.data_ptr() if gb is not None else None, 0, _stream(a)), fn_name)
     return ga, gb
 
 
@@ -361,3 +361,320 @@ def sinusoidal_embed(t: Tensor, dim: int) -> Tensor:
     L.check(lib.vita_sinusoidal_embed_f32(t.data_ptr(), out.data_ptr(), dim, t.numel(), dim, _stream(t)),
             "vita_sinusoidal_embed_f32")
     return out
+
+
+# --------------------------------------------------------------------------------------
+# training side: backward kernels (thin wrappers, used by the tests and the trainer)
+# --------------------------------------------------------------------------------------
+def linear_t(x: Tensor, w: Tensor, *, a_col: bool = False, b_col: bool = False, M: int, N: int, K: int,
+             bias: Optional[Tensor] = None, gate_scalar: Optional[float] = None, resid: Optional[Tensor] = None,
+             act: int = L.ACT_NONE, act_grad_z: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
+    """vita_linear_f32 with transposed operands: C[M,N] = resid + gs * act'(z) * (sum_k A(m,k) B(n,k) + bias) where
+    A(m,k) = x[k,m] if a_col else x[m,k], B(n,k) = w[k,n] if b_col else w[n,k] (dgrad / wgrad of nn.Linear)."""
+    lib = L.load()
+    x = _rows(x, "linear_t: x")
+    w = _rows(w, "linear_t: w")
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=x.device)
+    a = L.LinearArgs()
+    a.X, a.ldx, a.W, a.ldw = x.data_ptr(), _ld(x), w.data_ptr(), _ld(w)
+    a.bias = bias.data_ptr() if bias is not None else None
+    a.Y, a.ldy, a.M, a.N, a.K = out.data_ptr(), _ld(out), M, N, K
+    a.a_col, a.b_col, a.act = int(a_col), int(b_col), act
+    if act_grad_z is not None:
+        z = _rows(act_grad_z, "linear_t: act_grad_z")
+        a.act_grad_z, a.ld_act_grad_z = z.data_ptr(), _ld(z)
+    if gate_scalar is not None:
+        a.use_gate_scalar, a.gate_scalar = 1, float(gate_scalar)
+    if resid is not None:
+        a.resid, a.ld_resid = resid.data_ptr(), _ld(resid)
+    L.check(lib.vita_linear_f32(C.byref(a), _stream(x)), "vita_linear_f32 (transposed)")
+    return out
+
+
+def act_bwd(z: Tensor, dy: Tensor, act: int) -> Tensor:
+    lib = L.load()
+    z, dy = _f32(z, "act_bwd").contiguous(), _f32(dy, "act_bwd").contiguous()
+    dz = torch.empty_like(z)
+    L.check(lib.vita_act_bwd_f32(z.data_ptr(), dy.data_ptr(), dz.data_ptr(), z.numel(), act, _stream(z)), "vita_act_bwd_f32")
+    return dz
+
+
+def act_fwd(z: Tensor, act: int) -> Tensor:
+    lib = L.load()
+    z = _f32(z, "act_fwd").contiguous()
+    y = torch.empty_like(z)
+    L.check(lib.vita_act_fwd_f32(z.data_ptr(), y.data_ptr(), z.numel(), act, _stream(z)), "vita_act_fwd_f32")
+    return y
+
+
+def gate_bwd(dy: Tensor, z: Tensor, gate, need_dgate: bool = True):
+    """y = r + z*g: returns (dz, dgate_rows).  gate: (N) / (M,N) tensor or a python float."""
+    lib = L.load()
+    dy, z = _f32(dy, "gate_bwd").contiguous(), _f32(z, "gate_bwd").contiguous()
+    M, N = dy.shape
+    dz = torch.empty_like(dy)
+    dg = torch.empty_like(dy) if need_dgate else None
+    if isinstance(gate, float):
+        gp, ldg, gs = None, 0, gate
+    else:
+        gate = gate.contiguous()
+        gp, ldg, gs = gate.data_ptr(), (0 if gate.dim() == 1 else N), 0.0
+    L.check(lib.vita_gate_bwd_f32(dy.data_ptr(), z.data_ptr(), gp, ldg, gs, dz.data_ptr(),
+                                  dg.data_ptr() if dg is not None else None, N, M, N, _stream(dy)), "vita_gate_bwd_f32")
+    return dz, dg
+
+
+def layernorm_modulate_bwd(x: Tensor, dy: Tensor, mul: Tensor, eps: float, mode: int, dx_init: Optional[Tensor] = None):
+    """Backward of layernorm_modulate: returns (dx [+ dx_init], dmul_rows, dadd_rows)."""
+    lib = L.load()
+    x, dy = _rows(x, "ln_bwd: x"), _rows(dy, "ln_bwd: dy")
+    M, H = x.shape
+    mul = mul.contiguous()
+    dx = dx_init.clone() if dx_init is not None else torch.empty_like(x)
+    dm, da = torch.empty((M, H), device=x.device), torch.empty((M, H), device=x.device)
+    L.check(lib.vita_layernorm_modulate_bwd_f32(x.data_ptr(), _ld(x), dy.data_ptr(), _ld(dy), mul.data_ptr(),
+                                                0 if mul.dim() == 1 else H, M, H, eps, mode, dx.data_ptr(), H,
+                                                1 if dx_init is not None else 0, dm.data_ptr(), da.data_ptr(), H, _stream(x)),
+            "vita_layernorm_modulate_bwd_f32")
+    return dx, dm, da
+
+
+def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) -> Tensor:
+    lib = L.load()
+    x = _rows(x, "colsum: x")
+    M, N = x.shape
+    if out is None:
+        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+    part = torch.empty(lib.vita_colsum_partials_count(N), dtype=torch.float32, device=x.device)
+    L.check(lib.vita_colsum_f32(x.data_ptr(), _ld(x), M, N, part.data_ptr(), out.data_ptr(), int(accumulate), _stream(x)),
+            "vita_colsum_f32")
+    return out
+
+
+def im2col_k5s2(x: Tensor) -> Tensor:
+    lib = L.load()
+    x = _f32(x, "im2col").contiguous()
+    B, Lin, Cc = x.shape
+    Lout = (Lin - 1) // 2 + 1
+    col = torch.empty((B * Lout, Cc * 5), dtype=torch.float32, device=x.device)
+    L.check(lib.vita_im2col_k5s2_f32(x.data_ptr(), col.data_ptr(), B, Lin, Cc, _stream(x)), "vita_im2col_k5s2_f32")
+    return col
+
+
+def col2im_k5s2(dcol: Tensor, B: int, Lin: int, Cc: int) -> Tensor:
+    lib = L.load()
+    dcol = _f32(dcol, "col2im").contiguous()
+    dx = torch.empty((B, Lin, Cc), dtype=torch.float32, device=dcol.device)
+    L.check(lib.vita_col2im_k5s2_f32(dcol.data_ptr(), dx.data_ptr(), B, Lin, Cc, _stream(dcol)), "vita_col2im_k5s2_f32")
+    return dx
+
+
+def nlc_ncl(x: Tensor, to_ncl: bool) -> Tensor:
+    lib = L.load()
+    x = _f32(x, "nlc_ncl").contiguous()
+    if to_ncl:
+        B, Ln, Cc = x.shape
+        out = torch.empty((B, Cc, Ln), dtype=torch.float32, device=x.device)
+    else:
+        B, Cc, Ln = x.shape
+        out = torch.empty((B, Ln, Cc), dtype=torch.float32, device=x.device)
+    L.check(lib.vita_nlc_ncl_f32(x.data_ptr(), out.data_ptr(), B, Ln, Cc, int(to_ncl), _stream(x)), "vita_nlc_ncl_f32")
+    return out
+
+
+def cfm_interpolate_bwd(dxt: Tensor, dut: Tensor, t: Tensor, pair_j=None, pair_i=None):
+    lib = L.load()
+    dxt, dut, t = dxt.contiguous(), dut.contiguous(), t.contiguous()
+    B, D = dxt.shape
+    pair_i, pair_j = _idx(pair_i, dxt.device), _idx(pair_j, dxt.device)
+    d0, d1 = torch.empty_like(dxt), torch.empty_like(dxt)
+    L.check(lib.vita_cfm_interpolate_bwd_f32(dxt.data_ptr(), dut.data_ptr(), t.data_ptr(),
+                                             pair_i.data_ptr() if pair_i is not None else None,
+                                             pair_j.data_ptr() if pair_j is not None else None,
+                                             d0.data_ptr(), d1.data_ptr(), B, D, 0, _stream(dxt)), "vita_cfm_interpolate_bwd_f32")
+    return d0, d1
+
+
+def sumsq(x: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    lib = L.load()
+    x = _f32(x, "sumsq").contiguous()
+    part = torch.empty(lib.vita_loss_partials_count(), dtype=torch.float32, device=x.device)
+    if out is None:
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+    L.check(lib.vita_sumsq_f32(x.data_ptr(), x.numel(), part.data_ptr(), out.data_ptr(), _stream(x)), "vita_sumsq_f32")
+    return out
+
+
+def adamw_ema_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, ema: Optional[Tensor], *, step: int, lr: float,
+                   betas=(0.95, 0.999), eps: float = 1e-8, weight_decay: float = 1e-6, gnorm_sq: Optional[Tensor] = None,
+                   max_norm: float = 0.0, grad_scale: float = 1.0, ema_decay: float = 0.0) -> None:
+    """In-place fused clip + AdamW + EMA over flat fp32 buffers (see vita_adamw_ema_step_f32)."""
+    lib = L.load()
+    for t_ in (p, g, m, v) + ((ema,) if ema is not None else ()):
+        _f32(t_, "adamw_ema_step")
+        if not t_.is_contiguous():
+            raise L.VitaHipError("adamw_ema_step: buffers must be contiguous")
+    L.check(lib.vita_adamw_ema_step_f32(p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(),
+                                        ema.data_ptr() if ema is not None else None, p.numel(),
+                                        gnorm_sq.data_ptr() if gnorm_sq is not None else None, max_norm, grad_scale, lr,
+                                        betas[0], betas[1], eps, weight_decay, step, ema_decay, _stream(p)),
+            "vita_adamw_ema_step_f32")
+
+
+# --------------------------------------------------------------------------------------
+# whole-policy descriptor and the fused training step
+# --------------------------------------------------------------------------------------
+def _dev_f32(sd: Mapping[str, Tensor], key: str, device, strict: bool) -> Tensor:
+    t = sd[key]
+    if strict:
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise L.VitaHipError(f"{key}: gradient / training tensors must already be contiguous fp32 on the GPU")
+        return t.detach()
+    return _prep(sd, key, device)
+
+
+def _fill_flow(w, g, prefix: str, sd) -> None:
+    in_w = g(prefix + "input_proj.weight")
+    w.H, w.D = in_w.shape
+    w.TE = g(prefix + "time_embed.1.weight").shape[1]
+    n = 0
+    while f"{prefix}layers.{n}.mlp.fc1.weight" in sd:
+        n += 1
+    if n > L.MAX_LAYERS:
+        raise L.VitaHipError(f"flow net has {n} layers; the ABI supports {L.MAX_LAYERS}")
+    w.L = n
+    w.FF = g(prefix + "layers.0.mlp.fc1.weight").shape[0] if n else w.H
+    w.in_w, w.in_b = in_w.data_ptr(), g(prefix + "input_proj.bias").data_ptr()
+    w.te1_w, w.te1_b = g(prefix + "time_embed.1.weight").data_ptr(), g(prefix + "time_embed.1.bias").data_ptr()
+    w.te3_w, w.te3_b = g(prefix + "time_embed.3.weight").data_ptr(), g(prefix + "time_embed.3.bias").data_ptr()
+    for l in range(n):
+        w.fc1_w[l] = g(f"{prefix}layers.{l}.mlp.fc1.weight").data_ptr()
+        w.fc1_b[l] = g(f"{prefix}layers.{l}.mlp.fc1.bias").data_ptr()
+        w.fc2_w[l] = g(f"{prefix}layers.{l}.mlp.fc2.weight").data_ptr()
+        w.fc2_b[l] = g(f"{prefix}layers.{l}.mlp.fc2.bias").data_ptr()
+        w.mod_w[l] = g(f"{prefix}layers.{l}.time_modulator.1.weight").data_ptr()
+        w.mod_b[l] = g(f"{prefix}layers.{l}.time_modulator.1.bias").data_ptr()
+    w.norm_w, w.norm_b = g(prefix + "norm.weight").data_ptr(), g(prefix + "norm.bias").data_ptr()
+    w.out_w, w.out_b = g(prefix + "out_proj.weight").data_ptr(), g(prefix + "out_proj.bias").data_ptr()
+
+
+def _fill_dec(w, g, prefix: str, sd) -> None:
+    w.HD, w.D = g(prefix + "input_proj.weight").shape
+    w.OUT = g(prefix + "output_proj.weight").shape[0]
+    n = 0
+    while f"{prefix}layers.{n}.fc1.weight" in sd:
+        n += 1
+    w.NL = n
+    w.in_w, w.in_b = g(prefix + "input_proj.weight").data_ptr(), g(prefix + "input_proj.bias").data_ptr()
+    for i in range(n):
+        w.fc1_w[i] = g(f"{prefix}layers.{i}.fc1.weight").data_ptr()
+        w.fc1_b[i] = g(f"{prefix}layers.{i}.fc1.bias").data_ptr()
+        w.fc2_w[i] = g(f"{prefix}layers.{i}.fc2.weight").data_ptr()
+        w.fc2_b[i] = g(f"{prefix}layers.{i}.fc2.bias").data_ptr()
+    w.out_w, w.out_b = g(prefix + "output_proj.weight").data_ptr(), g(prefix + "output_proj.bias").data_ptr()
+
+
+def _fill_enc(w, g, prefix: str, sd, pred_horizon: int, latent_dim: int) -> None:
+    w.T, w.D = pred_horizon, latent_dim
+    if prefix + "latent_proj.weight" in sd:        # CNNActionEncoder, action_ae.py:282-327
+        w.kind = L.ENC_CNN
+        n = 0
+        while f"{prefix}encoder.{2 * n}.weight" in sd:
+            n += 1
+        w.NL = n
+        c0 = g(f"{prefix}encoder.0.weight")
+        w.C, w.A = c0.shape[0], c0.shape[1]
+        for i in range(n):
+            w.w1[i] = g(f"{prefix}encoder.{2 * i}.weight").data_ptr()
+            w.b1[i] = g(f"{prefix}encoder.{2 * i}.bias").data_ptr()
+        w.proj_w, w.proj_b = g(prefix + "latent_proj.weight").data_ptr(), g(prefix + "latent_proj.bias").data_ptr()
+    else:                                          # SimpleActionEncoder, :111-170
+        w.kind = L.ENC_SIMPLE
+        pw = g(prefix + "input_proj.weight")
+        w.C, w.A = pw.shape
+        n = 0
+        while f"{prefix}layers.{n}.fc1.weight" in sd:
+            n += 1
+        w.NL = n
+        for i in range(n):
+            w.w1[i] = g(f"{prefix}layers.{i}.fc1.weight").data_ptr()
+            w.b1[i] = g(f"{prefix}layers.{i}.fc1.bias").data_ptr()
+            w.w2[i] = g(f"{prefix}layers.{i}.fc2.weight").data_ptr()
+            w.b2[i] = g(f"{prefix}layers.{i}.fc2.bias").data_ptr()
+        w.proj_w, w.proj_b = pw.data_ptr(), g(prefix + "input_proj.bias").data_ptr()
+
+
+class PolicyHandle:
+    """vita_policy_weights over a state dict with the reference's keys.  With strict=True the
+    tensors are used in place (they must be contiguous fp32 on the GPU): that is what a gradient descriptor needs,
+    since the kernels write into them."""
+
+    def __init__(self, sd: Mapping[str, Tensor], device, pred_horizon: int = 16, strict: bool = False):
+        device = torch.device(device)
+        self.device = device
+        self.t = {}
+        g = lambda k: self.t.setdefault(k, _dev_f32(sd, k, device, strict))  # noqa: E731
+        w = L.PolicyWeights()
+        ow = g("obs_encoder.weight")
+        w.O = ow.shape[1]
+        w.obs_w, w.obs_b = ow.data_ptr(), g("obs_encoder.bias").data_ptr()
+        _fill_flow(w.flow, g, "flow_net.", sd)
+        _fill_dec(w.dec, g, "action_decoder.", sd)
+        _fill_enc(w.enc, g, "action_encoder.", sd, pred_horizon, ow.shape[0])
+        self.w = w
+        self.O, self.D, self.T, self.A, self.OUT = w.O, w.flow.D, w.enc.T, w.enc.A, w.dec.OUT
+
+
+def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
+                enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5) -> "L.LossConfig":
+    if recon not in ("l1", "l2"):
+        raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")   # vita_policy.py:71
+    c = L.LossConfig()
+    c.num_steps, c.recon_l1, c.decode_flow_latents = num_steps, int(recon == "l1"), int(decode_flow_latents)
+    c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
+    return c
+
+
+def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, *, grads: Optional[PolicyHandle] = None,
+                 pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None):
+    """VitaPolicy.compute_loss (+ backward when `grads` is given), vita_policy.py:112-189.  Returns
+    (losses (8,) device tensor indexed as _lib.LOSS_NAMES, d_obs_features or None).  No host sync."""
+    lib = L.load()
+    obs_features = _rows(obs_features, "compute_loss: obs_features")
+    actions = _f32(actions, "compute_loss: actions").contiguous()
+    t = _f32(t, "compute_loss: t").contiguous()
+    B = obs_features.shape[0]
+    if obs_features.shape[1] != pw.O or tuple(actions.shape) != (B, pw.T, pw.A) or tuple(t.shape) != (B,):
+        raise L.VitaHipError(f"compute_loss: obs {tuple(obs_features.shape)} / actions {tuple(actions.shape)} / t {tuple(t.shape)} "
+                             f"do not match O={pw.O}, T={pw.T}, A={pw.A}")
+    dev = obs_features.device
+    pair_i, pair_j = _idx(pair_i, dev), _idx(pair_j, dev)
+    if losses is None:
+        losses = torch.empty(L.LOSS_COUNT, dtype=torch.float32, device=dev)
+    dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
+    ev = None
+    if grad_ready_events is not None:
+        ev = (L.c_fp * 3)(*[e.cuda_event if e is not None else None for e in grad_ready_events])
+    nbytes = lib.vita_compute_loss_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
+    ws = workspace(dev, nbytes)
+    L.check(lib.vita_compute_loss_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
+                                      obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(),
+                                      pair_i.data_ptr() if pair_i is not None else None,
+                                      pair_j.data_ptr() if pair_j is not None else None, B, losses.data_ptr(),
+                                      dobs.data_ptr() if dobs is not None else None, pw.O, ev, ws.data_ptr(), ws.numel(),
+                                      _stream(obs_features)), "vita_compute_loss_f32")
+    return losses, dobs
+
+
+def action_encoder_forward(pw: PolicyHandle, actions: Tensor) -> Tensor:
+    """CNNActionEncoder.forward / SimpleActionEncoder.forward (action_ae.py:318-327, 161-170)."""
+    lib = L.load()
+    actions = _f32(actions, "action_encoder_forward").contiguous()
+    B = actions.shape[0]
+    z = torch.empty((B, pw.D), dtype=torch.float32, device=actions.device)
+    nbytes = lib.vita_action_encoder_workspace_bytes(C.byref(pw.w.enc), B)
+    ws = workspace(actions.device, nbytes)
+    L.check(lib.vita_action_encoder_forward_f32(C.byref(pw.w.enc), actions.data_ptr(), z.data_ptr(), pw.D, B, ws.data_ptr(),
+                                                ws.numel(), _stream(actions)), "vita_action_encoder_forward_f32")
+    return z
