@@ -198,10 +198,13 @@ int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, c
 int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float* t, const int64_t* pair_i, const int64_t* pair_j,
                                  float* dx0, float* dx1, int32_t B, int32_t D, int32_t accumulate, vita_stream_t stream);
 
-/* (x - mean) / (std + 1e-8) and x*std + mean over the last dim C, broadcast over rows:
- * Normalize.forward / Unnormalize.forward, normalize.py:38-46,62-70. */
-int vita_normalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, vita_stream_t stream);
-int vita_unnormalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, vita_stream_t stream);
+/* (x - mean) / (std + 1e-8) and x*std + mean for x viewed as (rows, C, inner) with per-C statistics:
+ * Normalize.forward / Unnormalize.forward, normalize.py:38-46,62-70.  inner = 1 for state / action vectors
+ * (stats of shape (C)); inner = H*W for images with stats of shape (C,1,1). */
+int vita_normalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, int64_t inner,
+                       vita_stream_t stream);
+int vita_unnormalize_f32(const float* x, const float* mean, const float* std, float* y, int64_t rows, int32_t C, int64_t inner,
+                         vita_stream_t stream);
 
 /* LayerNorm over the last dim H fused with its following elementwise op, one pass over x:
  *   mode VITA_PRO_LN_MOD   : y = LN(x; no affine, eps) * (1 + mul) + add   — FlowNetLayer, simple_flow_net.py:44-45

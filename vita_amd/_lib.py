@@ -139,8 +139,8 @@ SIGNATURES = {
     "vita_sumsq_f32": (C.c_int, [c_fp, C.c_int64, c_fp, c_fp, c_fp]),
     "vita_adamw_ema_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, c_fp, C.c_float, C.c_float, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, c_fp]),
-    "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
-    "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, c_fp]),
+    "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
+    "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,
                                               c_fp, C.c_int64, c_fp, C.c_int64, c_fp]),
     "vita_sinusoidal_embed_f32": (C.c_int, [c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp]),

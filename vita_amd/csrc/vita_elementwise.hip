@@ -138,10 +138,10 @@ __global__ __launch_bounds__(EW_THREADS) void cfm_kernel(const float* __restrict
 // ---- (un)normalise ---------------------------------------------------------------------------
 template <bool UN>
 __global__ __launch_bounds__(EW_THREADS) void norm_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                                        const float* __restrict__ sd, float* __restrict__ y, int64_t n, int C) {
+                                                        const float* __restrict__ sd, float* __restrict__ y, int64_t n, int C, int64_t inner) {
     const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
     for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
-        const int c = (int)(i % C);
+        const int c = (int)((i / inner) % C);
         if (UN) y[i] = x[i] * sd[c] + mean[c];
         else y[i] = (x[i] - mean[c]) / (sd[c] + 1e-8f);
     }
@@ -297,21 +297,23 @@ int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, c
     return VITA_OK;
 }
 
-int vita_normalize_f32(const float* x, const float* mean, const float* sd, float* y, int64_t rows, int32_t C, vita_stream_t stream) {
+int vita_normalize_f32(const float* x, const float* mean, const float* sd, float* y, int64_t rows, int32_t C, int64_t inner,
+                       vita_stream_t stream) {
     VITA_REQUIRE(x && mean && sd && y, "vita_normalize_f32: null pointer");
-    VITA_REQUIRE(rows >= 0 && C > 0, "vita_normalize_f32: bad shape");
+    VITA_REQUIRE(rows >= 0 && C > 0 && inner >= 1, "vita_normalize_f32: bad shape");
     if (rows == 0) return VITA_OK;
-    hipLaunchKernelGGL((norm_kernel<false>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, mean, sd, y,
-                       rows * C, C);
+    hipLaunchKernelGGL((norm_kernel<false>), dim3(ew_grid(rows * C * inner)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, mean, sd, y,
+                       rows * C * inner, C, inner);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
-int vita_unnormalize_f32(const float* x, const float* mean, const float* sd, float* y, int64_t rows, int32_t C, vita_stream_t stream) {
+int vita_unnormalize_f32(const float* x, const float* mean, const float* sd, float* y, int64_t rows, int32_t C, int64_t inner,
+                         vita_stream_t stream) {
     VITA_REQUIRE(x && mean && sd && y, "vita_unnormalize_f32: null pointer");
-    VITA_REQUIRE(rows >= 0 && C > 0, "vita_unnormalize_f32: bad shape");
+    VITA_REQUIRE(rows >= 0 && C > 0 && inner >= 1, "vita_unnormalize_f32: bad shape");
     if (rows == 0) return VITA_OK;
-    hipLaunchKernelGGL((norm_kernel<true>), dim3(ew_grid(rows * C)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, mean, sd, y,
-                       rows * C, C);
+    hipLaunchKernelGGL((norm_kernel<true>), dim3(ew_grid(rows * C * inner)), dim3(EW_THREADS), 0, (hipStream_t)stream, x, mean, sd, y,
+                       rows * C * inner, C, inner);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }

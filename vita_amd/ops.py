@@ -316,16 +316,25 @@ def cfm_interpolate(x0: Tensor, x1: Tensor, t: Tensor, pair_j: Optional[Tensor] 
 
 
 def _norm(fn_name: str, x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
+    """Stats of shape (C) act on the last dim; stats of shape (C,1,..,1) act on dim -mean.dim() (image statistics)."""
     lib = L.load()
     x = _f32(x, fn_name).contiguous()
+    trailing = 0
+    while mean.dim() > 1 + trailing and mean.shape[-1 - trailing] == 1:
+        trailing += 1
+    if mean.dim() != 1 + trailing or std.shape != mean.shape:
+        raise L.VitaHipError(f"{fn_name}: statistics must be (C) or (C,1,..,1), got {tuple(mean.shape)} / {tuple(std.shape)}")
+    Cdim = mean.shape[0]
+    if x.dim() < 1 + trailing or x.shape[x.dim() - 1 - trailing] != Cdim:
+        raise L.VitaHipError(f"{fn_name}: x {tuple(x.shape)} does not match statistics {tuple(mean.shape)}")
+    inner = 1
+    for d in x.shape[x.dim() - trailing:]:
+        inner *= d
     mean = _f32(mean, fn_name).contiguous().reshape(-1)
     std = _f32(std, fn_name).contiguous().reshape(-1)
-    Cdim = mean.numel()
-    if x.shape[-1] != Cdim or std.numel() != Cdim:
-        raise L.VitaHipError(f"{fn_name}: last dim {x.shape[-1]} != stats dim {Cdim}")
     y = torch.empty_like(x)
-    L.check(getattr(lib, fn_name)(x.data_ptr(), mean.data_ptr(), std.data_ptr(), y.data_ptr(), x.numel() // Cdim, Cdim,
-                                  _stream(x)), fn_name)
+    L.check(getattr(lib, fn_name)(x.data_ptr(), mean.data_ptr(), std.data_ptr(), y.data_ptr(), x.numel() // (Cdim * inner), Cdim,
+                                  inner, _stream(x)), fn_name)
     return y
 
 

@@ -1,0 +1,539 @@
+"""VitaPolicy — drop-in for flare.policies.vita.vita_policy.VitaPolicy on the vision-latent -> action-latent
+flow-matching path (same constructor, methods, metric keys and state-dict keys).
+
+PyTorch holds the parameters (device memory, state_dict, optimizer compatibility); every FLOP of
+generate_actions / select_action / compute_loss runs in libvita_hip.so through the C ABI:
+  * inference:  vita_generate_actions_f32  (obs_encoder -> K Euler steps -> decoder, one call)
+  * training:   vita_compute_loss_f32      (forward + hand-written backward, one call)
+There is no CPU or torch fallback: on a CPU tensor the ops raise VitaHipError.
+
+Out of scope here: the ResNet18 observer.  `observer` is pluggable (any nn.Module mapping the
+batch to (B, O) features); the default FeatureObserver consumes precomputed camera latents
+(batch["observation.features"], 512 per camera) + the state, in the reference's concat order
+(resnet_observer.py:80-97: state first).
+"""
+from __future__ import annotations
+
+import math
+import os
+import time
+from collections import deque
+from typing import Optional
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .flow import get_flow_matcher
+
+FLOW_NET_NAMES = ("simple_flow_net", "simple")  # vita.yaml:28 ships "simple", vita_policy.py:84 accepts "simple_flow_net"
+
+
+# ----------------------------------------------------------------------------------------------------
+# normalisation (flare/utils/normalize.py) — same module/parameter names, HIP kernels for the arithmetic
+# ----------------------------------------------------------------------------------------------------
+def _stats_buffers(module: nn.Module, keys, stats) -> None:
+    for key, stat in stats.items():
+        if key not in keys:
+            continue
+        buf = nn.ParameterDict({
+            "mean": nn.Parameter(torch.as_tensor(stat["mean"], dtype=torch.float32).clone(), requires_grad=False),
+            "std": nn.Parameter(torch.as_tensor(stat["std"], dtype=torch.float32).clone(), requires_grad=False),
+        })
+        setattr(module, "buffer_" + key.replace(".", "_"), buf)
+
+
+class Normalize(nn.Module):
+    """normalize.py:25-46: (x - mean) / (std + 1e-8) per key."""
+    _fn = staticmethod(ops.normalize)
+
+    def __init__(self, keys, stats):
+        super().__init__()
+        self.keys = list(keys)
+        _stats_buffers(self, self.keys, stats)
+
+    @torch.no_grad()
+    def forward(self, batch):
+        batch = dict(batch)
+        for key in self.keys:
+            name = "buffer_" + key.replace(".", "_")
+            if key not in batch or not hasattr(self, name):
+                continue   # e.g. image keys when the batch carries precomputed camera latents
+            buf = getattr(self, name)
+            batch[key] = self._fn(batch[key], buf["mean"], buf["std"])
+        return batch
+
+
+class Unnormalize(Normalize):
+    """normalize.py:49-70: x * std + mean per key."""
+    _fn = staticmethod(ops.unnormalize)
+
+
+# ----------------------------------------------------------------------------------------------------
+# parameter containers with the reference's state-dict keys (never called: the kernels read the tensors)
+# ----------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter container: the arithmetic runs in libvita_hip.so (see VitaPolicy)")
+
+
+def _mlp(in_f, hid_f, out_f):
+    m = _Holder()
+    m.fc1, m.fc2 = nn.Linear(in_f, hid_f), nn.Linear(hid_f, out_f)
+    return m
+
+
+def _xavier(mod: nn.Module):
+    for m in mod.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.zeros_(m.bias)
+
+
+def _orthogonal(mod: nn.Module):
+    for m in mod.modules():
+        if isinstance(m, (nn.Linear, nn.Conv1d)):
+            nn.init.orthogonal_(m.weight.data)
+            m.bias.data.fill_(0.0)
+
+
+def make_flow_net(D, H, L_, mlp_ratio, time_embed_dim=256) -> nn.Module:
+    """SimpleFlowNet's parameters and init (simple_flow_net.py:52-97; note the Xavier pass re-initialises the
+    zero-initialised modulators)."""
+    net = _Holder()
+    net.input_proj = nn.Linear(D, H)
+    net.time_embed = nn.Sequential(nn.Identity(), nn.Linear(time_embed_dim, 4 * time_embed_dim), nn.Mish(),
+                                   nn.Linear(4 * time_embed_dim, H))
+    layers = []
+    for _ in range(L_):
+        layer = _Holder()
+        layer.mlp = _mlp(H, int(H * mlp_ratio), H)
+        layer.time_modulator = nn.Sequential(nn.SiLU(), nn.Linear(H, 3 * H))
+        layers.append(layer)
+    net.layers = nn.ModuleList(layers)
+    net.norm = nn.LayerNorm(H)
+    net.out_proj = nn.Linear(H, D)
+    _xavier(net)
+    nn.init.normal_(net.time_embed[1].weight, std=0.02)
+    nn.init.normal_(net.time_embed[3].weight, std=0.02)
+    return net
+
+
+def make_action_encoder(kind, T, A, D, hidden, num_layers) -> nn.Module:
+    enc = _Holder()
+    if kind == "cnn":                                   # action_ae.py:282-316
+        if T // (2 ** num_layers) < 1 or T % (2 ** num_layers):
+            raise ValueError(f"cnn encoder: pred_horizon {T} must be a multiple of 2^num_layers ({num_layers})")
+        mods, c = [], A
+        for _ in range(num_layers):
+            mods += [nn.Conv1d(c, hidden, kernel_size=5, stride=2, padding=2), nn.ReLU()]
+            c = hidden
+        enc.encoder = nn.Sequential(*mods)
+        enc.latent_proj = nn.Linear(hidden * (T // (2 ** num_layers)), D)
+        _orthogonal(enc)
+    elif kind == "simple":                              # action_ae.py:111-159
+        ald = D // T
+        enc.input_proj = nn.Linear(A, ald)
+        enc.layers = nn.ModuleList([_mlp(ald, 4 * ald, ald) for _ in range(num_layers)])
+        _xavier(enc)
+    elif kind == "transformer":
+        raise NotImplementedError("encoder_type 'transformer' is outside this build's hot path (SURVEY.md section 2 #3)")
+    else:
+        raise ValueError(f"Unknown encoder type: {kind}")   # action_ae.py:374
+    return enc
+
+
+def make_action_decoder(kind, T, A, D, hidden, num_layers) -> nn.Module:
+    if kind != "simple":
+        raise ValueError(f"Unknown encoder type: {kind}")   # sic, action_ae.py:386
+    dec = _Holder()
+    dec.input_proj = nn.Linear(D, hidden)                   # action_ae.py:239-253
+    dec.output_proj = nn.Linear(hidden, T * A)
+    dec.layers = nn.ModuleList([_mlp(hidden, hidden, hidden) for _ in range(num_layers)])
+    _xavier(dec)
+    return dec
+
+
+class FeatureObserver(nn.Module):
+    """Stand-in for ResNetObserver._observe_flattened (resnet_observer.py:80-97) when the camera latents are
+    precomputed: cat([state.flatten(1), features.flatten(1)], dim=1).  Pure data movement."""
+
+    def __init__(self, state_key: str, feature_key: str = "observation.features"):
+        super().__init__()
+        self.state_key, self.feature_key = state_key, feature_key
+
+    def forward(self, batch):
+        if self.feature_key not in batch:
+            raise KeyError(f"batch has no '{self.feature_key}': pass precomputed camera latents, or construct VitaPolicy with "
+                           "observer=<module producing (B, O) features> (the ResNet18 observer is out of this build's scope)")
+        return torch.cat([batch[self.state_key].flatten(start_dim=1), batch[self.feature_key].flatten(start_dim=1)], dim=1)
+
+
+# ----------------------------------------------------------------------------------------------------
+class _FusedLoss(torch.autograd.Function):
+    """Makes `loss.backward()` of the reference trainer (policy_trainer.py:82) work: the forward already ran the
+    fused forward+backward; backward hands the staged gradients to autograd (scaled by the incoming grad)."""
+
+    @staticmethod
+    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, *params):
+        pw, gw, gsd = policy._train_handles(stage=True)
+        staged = [gsd[k] for k, _ in policy.hot_path_named_parameters()]
+        need_dobs = obs_features.requires_grad
+        losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
+                                        need_dobs=need_dobs)
+        ctx.staged, ctx.dobs = staged, dobs
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), losses
+
+    @staticmethod
+    def backward(ctx, gout, _):
+        grads = tuple(g * gout for g in ctx.staged)
+        dobs = ctx.dobs * gout if ctx.dobs is not None else None
+        return (None, dobs, None, None, None, None) + grads
+
+
+class VitaPolicy(nn.Module):
+    """flare/policies/vita/vita_policy.py:36-283 + base_policy.py:15-89."""
+
+    # flat-buffer segment order = the order gradients become final in the backward pass (vita_loss_step.hip)
+    BUCKET_PREFIXES = (("action_decoder.",), ("flow_net.",), ("action_encoder.", "obs_encoder."))
+
+    def __init__(self, config, stats, observer: Optional[nn.Module] = None):
+        super().__init__()
+        self.config = config
+        self.stats = stats
+        pol, task = config.policy, config.task
+        # base_policy.py:22-30
+        self.pred_horizon = pol.pred_horizon
+        self.action_horizon = pol.action_horizon
+        self.obs_horizon = pol.obs_horizon
+        self.action_dim = task.action_dim
+        self.normalize_inputs = Normalize(list(task.image_keys) + [task.state_key], stats)
+        self.normalize_targets = Normalize([task.action_key], stats)
+        self.unnormalize_outputs = Unnormalize([task.action_key], stats)
+        self._action_queue = None
+        # vita_policy.py:41-74
+        self.num_sampling_steps = pol.flow_matcher.num_sampling_steps
+        self.observer = observer if observer is not None else FeatureObserver(task.state_key)
+        self.obs_dim = len(task.image_keys) * 512 + task.state_dim
+        self.FM = get_flow_matcher(**dict(pol.flow_matcher))
+        ae = pol.action_ae
+        net = ae.net
+        self.use_action_vae = ae.use_variational
+        self.latent_dim = net.latent_dim
+        self.freeze_action_encoder = ae.freeze_encoder
+        self.freeze_action_decoder = ae.freeze_decoder
+        self.flow_action_recon_weight = ae.flow_recon_weight
+        self.enc_action_recon_weight = ae.enc_recon_weight
+        self.action_kl_weight = ae.kl_weight
+        if ae.recon_loss_type not in ("l1", "l2"):
+            raise ValueError(f"Unsupported recon_loss_type: {ae.recon_loss_type}. Use 'l1' or 'l2'.")   # :71
+        self.enc_contrastive_weight = pol.vita.enc_contrastive_weight
+        self.flow_contrastive_weight = pol.vita.flow_contrastive_weight
+        unsupported = []
+        if self.use_action_vae: unsupported.append("action_ae.use_variational")
+        if self.freeze_action_encoder or self.freeze_action_decoder: unsupported.append("action_ae.freeze_*")
+        if self.enc_contrastive_weight > 0 or self.flow_contrastive_weight > 0: unsupported.append("vita.*_contrastive_weight > 0")
+        if unsupported:
+            raise NotImplementedError("non-default branches outside this build's fused training path: " + ", ".join(unsupported))
+        self.obs_encoder = nn.Linear(self.obs_dim, self.latent_dim)                                      # :77
+        self.action_encoder = make_action_encoder(net.encoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
+                                                  net.enc_hidden_dim, net.num_layers)                   # :101-110
+        self.action_decoder = make_action_decoder(net.decoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
+                                                  net.dec_hidden_dim, net.num_layers)
+        fn = pol.flow_net
+        if fn.name not in FLOW_NET_NAMES:
+            raise ValueError(f"Unsupported flow_net: {fn.name}")                                         # :89
+        if float(fn.get("dropout", 0.0)) != 0.0:
+            raise NotImplementedError("flow_net.dropout > 0 is not implemented (vita.yaml:32 uses 0.0)")
+        self.flow_net = make_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)      # :90-97
+        self._loss_cfg = ops.loss_config(num_steps=self.num_sampling_steps, recon=ae.recon_loss_type,
+                                         decode_flow_latents=bool(pol.vita.decode_flow_latents),
+                                         consistency_weight=float(pol.vita.consistency_weight),
+                                         enc_recon_weight=float(self.enc_action_recon_weight),
+                                         flow_recon_weight=float(self.flow_action_recon_weight))
+        self._flat = self._flat_grad = None
+        self._cache = {}
+        self.bucket_ranges = None
+        self.reset()
+
+    # -- parameter plumbing --------------------------------------------------------------------------
+    def hot_path_named_parameters(self):
+        """(name, parameter) of the trainable hot-path tensors in flat-buffer order."""
+        named = dict(self.named_parameters())
+        out = []
+        for prefixes in self.BUCKET_PREFIXES:
+            for k, p in named.items():
+                if k.startswith(prefixes) and p.requires_grad:
+                    out.append((k, p))
+        return out
+
+    def flatten_parameters(self):
+        """Re-home the hot-path parameters (and their .grad) as views of two flat fp32 device buffers, so the data-parallel
+        trainer all-reduces contiguous buckets and the optimizer is one fused kernel.  Call after .to(device)."""
+        named = self.hot_path_named_parameters()
+        dev = named[0][1].device
+        if dev.type != "cuda":
+            raise L.VitaHipError("flatten_parameters: move the policy to the GPU first (policy.to('cuda:0'))")
+        n = sum(p.numel() for _, p in named)
+        flat = torch.empty(n, dtype=torch.float32, device=dev)
+        flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off, ranges, bucket = 0, [], 0
+        starts = [0]
+        for k, p in named:
+            while not k.startswith(self.BUCKET_PREFIXES[bucket]):
+                bucket += 1
+                starts.append(off)
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        starts.append(off)
+        while len(starts) < len(self.BUCKET_PREFIXES) + 1:
+            starts.append(off)
+        ranges = [(starts[i], starts[i + 1]) for i in range(len(self.BUCKET_PREFIXES))]
+        self._flat, self._flat_grad, self.bucket_ranges = flat, flat_grad, ranges
+        self._cache = {}
+        return flat, flat_grad
+
+    def _key(self):
+        w = self.obs_encoder.weight
+        return (w.data_ptr(), w.device, self.flow_net.out_proj.bias.data_ptr())
+
+    def _infer_handles(self):
+        c = self._cache.get("infer")
+        if c is None or c[0] != self._key():
+            sd = {k: p.data for k, p in self.named_parameters()}
+            dev = self.obs_encoder.weight.device
+            c = (self._key(), ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), ops.PolicyHandle(sd, dev, self.pred_horizon))
+            self._cache["infer"] = c
+        return c[1], c[2], c[3]
+
+    def _train_handles(self, stage: bool = False):
+        """(weights, gradient descriptor, {name: gradient tensor}).  stage=False: the gradient tensors ARE the parameters'
+        .grad (views of the flat gradient buffer after flatten_parameters) — the native trainer's path.  stage=True: separate
+        staging tensors, for the autograd bridge (autograd then accumulates them into .grad itself)."""
+        slot = "train_stage" if stage else "train"
+        c = self._cache.get(slot)
+        if c is None or c[0] != self._key():
+            named = self.hot_path_named_parameters()
+            sd = {k: p.data for k, p in named}
+            if stage:
+                n = sum(p.numel() for _, p in named)
+                buf = torch.zeros(n, dtype=torch.float32, device=named[0][1].device)
+                gsd, off = {}, 0
+                for k, p in named:
+                    gsd[k] = buf[off:off + p.numel()].view_as(p)
+                    off += p.numel()
+            elif self._flat_grad is not None:
+                gsd = {k: p.grad for k, p in named}
+            else:
+                gsd = {k: torch.zeros_like(p.data) for k, p in named}
+            dev = self.obs_encoder.weight.device
+            c = (self._key(), ops.PolicyHandle(sd, dev, self.pred_horizon, strict=True),
+                 ops.PolicyHandle(gsd, dev, self.pred_horizon, strict=True), gsd)
+            self._cache[slot] = c
+        return c[1], c[2], c[3]
+
+    # -- base_policy.py API ----------------------------------------------------------------------------
+    def get_action_indices(self):
+        return list(range(self.pred_horizon))
+
+    def get_observation_indices(self):
+        return list(range(self.obs_horizon))
+
+    def reset(self):
+        self._action_queue = deque([], maxlen=self.action_horizon)
+
+    def forward(self, batch):
+        """base_policy.py:38-43."""
+        batch = self.normalize_inputs(batch)
+        batch = self.normalize_targets(batch)
+        return self.compute_loss(batch)
+
+    # -- the hot path -----------------------------------------------------------------------------------
+    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None):
+        """t ~ U(0,1) and the OT pairing, on the host as in the reference (flow_matchers.py:34 -> torchcfm)."""
+        if t is None:
+            t = torch.rand(batch_size).to(dev)
+        if self.FM.pairing == "exact" and pair_i is None and pair_j is None:
+            # the plan needs the latents: one encoder pass (forward only) — the reference pays the same sync
+            _, _, pw = self._infer_handles()
+            z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
+            z1 = ops.action_encoder_forward(pw, actions)
+            from .flow import exact_ot_pairing
+            pair_i, pair_j = exact_ot_pairing(z0, z1)
+        return t, pair_i, pair_j
+
+    def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None):
+        """Native training entry (no autograd): normalised batch -> losses (device float[8], _lib.LOSS_NAMES order), with
+        d loss / d parameter written into the parameters' .grad buffers.  No host synchronisation."""
+        obs_features = self.observer(batch)
+        actions = batch[self.config.task.action_key]
+        t, pair_i, pair_j = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions)
+        pw, gw, gsd = self._train_handles()
+        if self._flat_grad is None:
+            for (k, p) in self.hot_path_named_parameters():
+                p.grad = gsd[k]
+        out, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
+                                  grad_ready_events=grad_ready_events, losses=losses)
+        return out
+
+    def compute_loss(self, batch, *, t=None, pair_i=None, pair_j=None):
+        """vita_policy.py:112-189.  Returns (loss, metrics) with the reference's metric keys; `loss` supports
+        .backward() (drop-in for policy_trainer.py:79-82).  One device->host copy for all metrics (the reference
+        does one .item() per metric)."""
+        obs_features = self.observer(batch)
+        actions = batch[self.config.task.action_key]
+        t, pair_i, pair_j = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions)
+        if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
+            params = [p for _, p in self.hot_path_named_parameters()]
+            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, *params)
+        else:
+            _, _, pw = self._infer_handles()
+            losses, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j)
+            loss = losses[0]
+        vals = losses.detach().cpu().tolist()
+        metrics = {"loss": vals[1], "flow_loss": vals[1]}   # FM.compute_loss's own 'loss' entry is the flow loss (flow_matchers.py:39)
+        cfgv = self.config.policy.vita
+        if cfgv.decode_flow_latents:
+            if cfgv.consistency_weight > 0:
+                metrics["consistency_loss"] = vals[2]
+            if self.flow_action_recon_weight > 0:
+                metrics["flow_action_recon_loss"] = vals[3]
+        if self.enc_action_recon_weight > 0:
+            metrics["enc_action_recon_loss"] = vals[4]
+        return loss, metrics
+
+    @torch.no_grad()
+    def generate_actions(self, batch):
+        """vita_policy.py:191-208: observer features -> obs_encoder -> K Euler steps -> decoder, one C-ABI call."""
+        obs_features = self.observer(batch)
+        fw, dw, _ = self._infer_handles()
+        out = ops.generate_actions(self.obs_encoder.weight.data, self.obs_encoder.bias.data, fw, dw, obs_features,
+                                   self.num_sampling_steps)
+        return out.view(-1, self.pred_horizon, self.action_dim)
+
+    @torch.no_grad()
+    def select_action(self, batch):
+        """vita_policy.py:210-220."""
+        self.eval()
+        keep = list(self.config.task.image_keys) + [self.config.task.state_key, getattr(self.observer, "feature_key", None)]
+        batch = {k: v.unsqueeze(1) for k, v in batch.items() if k in keep}
+        batch = self.normalize_inputs(batch)
+        if len(self._action_queue) == 0:
+            actions = self.generate_actions(batch)
+            actions = actions[:, :self.action_horizon]
+            actions = self.unnormalize_outputs({"action": actions})["action"]
+            self._action_queue.extend(actions.transpose(0, 1))
+        return self._action_queue.popleft()
+
+    def validate(self, batch):
+        """base_policy.py:60-89 — the reference's chunks_per_sec meter (the benchmark's metric definition)."""
+        self.eval()
+        batch = self.normalize_inputs(batch)
+        ak = self.config.task.action_key
+        batch_size = batch[ak].shape[0]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        pred_norm = self.generate_actions(batch)
+        torch.cuda.synchronize()
+        gen_time_ms = (time.perf_counter() - t0) * 1000 / batch_size
+        pred = self.unnormalize_outputs({"action": pred_norm})["action"]
+        gt = batch[ak]
+        with torch.no_grad():
+            loss, metrics = self.compute_loss(batch)
+        metrics["action_mse"] = ops.mse_loss_fwd(pred, gt).item()
+        metrics["loss"] = loss.item()
+        total_actions = batch_size * self.action_horizon
+        metrics["time_per_chunk_ms"] = gen_time_ms
+        metrics["time_per_action_ms"] = gen_time_ms / total_actions
+        metrics["chunks_per_sec"] = 1000 / gen_time_ms
+        return metrics
+
+    def visualize(self, batch, num_samples: int = 1):
+        """Plotting is outside the hot path; the trainer treats the result as optional."""
+        return {}
+
+    # -- optimizer / schedule / EMA factories (vita_policy.py:222-237, base_policy.py:45-49) ---------------
+    def get_optimizer(self):
+        c = self.config
+        return torch.optim.AdamW(params=self.parameters(), lr=c.optimizer_lr, betas=tuple(c.optimizer_betas), eps=c.optimizer_eps,
+                                 weight_decay=c.optimizer_weight_decay)
+
+    def get_scheduler(self, optimizer, num_training_steps: int):
+        """diffusers==0.30.3 get_scheduler('cosine' | 'constant' | 'constant_with_warmup') restated (UNPINNED)."""
+        name, warm = self.config.scheduler_name, self.config.scheduler_warmup_steps
+        return torch.optim.lr_scheduler.LambdaLR(optimizer, lambda s: lr_lambda(name, s, warm, num_training_steps))
+
+    def get_ema(self):
+        return EMAModel(self.parameters(), power=self.config.ema_power) if self.config.use_ema else None
+
+    # -- checkpoints: model.safetensors as PyTorchModelHubMixin.save_pretrained writes it (policy_trainer.py:265) ----
+    def save_pretrained(self, save_directory: str):
+        from safetensors.torch import save_file
+        os.makedirs(save_directory, exist_ok=True)
+        save_file({k: v.detach().cpu().clone().contiguous() for k, v in self.state_dict().items()},
+                  os.path.join(save_directory, "model.safetensors"))
+
+    def load_pretrained(self, directory: str, strict: bool = False):
+        """checkpoints.py:121-153: model.safetensors, load_state_dict(strict=False)."""
+        from safetensors.torch import load_file
+        return self.load_state_dict(load_file(os.path.join(directory, "model.safetensors")), strict=strict)
+
+
+def lr_lambda(name: str, step: int, num_warmup_steps: int, num_training_steps: int) -> float:
+    if name == "constant":
+        return 1.0
+    if name == "constant_with_warmup":
+        return min(1.0, float(step) / float(max(1, num_warmup_steps)))
+    if name == "cosine":
+        if step < num_warmup_steps:
+            return float(step) / float(max(1, num_warmup_steps))
+        progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * progress)))
+    raise ValueError(f"scheduler {name!r} is not implemented (cosine, constant, constant_with_warmup)")
+
+
+def ema_decay(optimization_step: int, max_decay: float = 0.9999, min_decay: float = 0.0, inv_gamma: float = 1.0,
+              power: float = 2.0 / 3.0, use_ema_warmup: bool = False) -> float:
+    """diffusers==0.30.3 EMAModel.get_decay restated (UNPINNED).  The reference passes only `power`
+    (base_policy.py:45-49), so use_ema_warmup is False and decay = min((1+s)/(10+s), 0.9999)."""
+    step = max(0, optimization_step - 1)
+    if step <= 0:
+        return 0.0
+    cur = 1 - (1 + step / inv_gamma) ** -power if use_ema_warmup else (1 + step) / (10 + step)
+    return max(min(cur, max_decay), min_decay)
+
+
+class EMAModel:
+    """The slice of diffusers.training_utils.EMAModel the runner uses: step(parameters), copy_to, state_dict."""
+
+    def __init__(self, parameters, power: float = 2.0 / 3.0, decay: float = 0.9999):
+        self.shadow_params = [p.clone().detach() for p in parameters]
+        self.power, self.decay, self.optimization_step, self.cur_decay_value = power, decay, 0, 0.0
+
+    @torch.no_grad()
+    def step(self, parameters):
+        self.optimization_step += 1
+        d = ema_decay(self.optimization_step, max_decay=self.decay, power=self.power)
+        self.cur_decay_value = d
+        for s, p in zip(self.shadow_params, list(parameters)):
+            if p.requires_grad:
+                s.sub_((1 - d) * (s - p))
+            else:
+                s.copy_(p)
+
+    def copy_to(self, parameters):
+        for s, p in zip(self.shadow_params, list(parameters)):
+            p.data.copy_(s.to(p.device).data)
+
+    def state_dict(self):
+        return {"decay": self.decay, "power": self.power, "optimization_step": self.optimization_step,
+                "shadow_params": self.shadow_params}
+
+    def load_state_dict(self, sd):
+        self.decay, self.power, self.optimization_step = sd["decay"], sd["power"], sd["optimization_step"]
+        self.shadow_params = [p.clone() for p in sd["shadow_params"]]
