@@ -41,6 +41,9 @@ def main():
     ap.add_argument("--ode-steps", type=int, default=6)
     ap.add_argument("--task", default="hook_package", choices=sorted(TASKS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--train-batch", type=int, default=128, help="training rows per GPU (default_policy.yaml:34)")
+    ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0 = same as --steps)")
+    ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=512)
     args = ap.parse_args()
 
@@ -110,6 +113,57 @@ def main():
     lat_ms = (time.perf_counter() - t0) * 1e3 / n_lat
     f_step = 2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D
     lat_tflops = B * K * f_step / (lat_ms * 1e-3) / 1e12
+
+    # ---- training leg: data-parallel train_step (normalize -> fused fwd+bwd -> bucketed all-reduce -> clip+AdamW+EMA)
+    train = None
+    if not args.no_train:
+        from vita_amd.config import default_config
+        from vita_amd.policy import VitaPolicy
+        from vita_amd.trainer import PolicyTrainer
+        cfg = default_config(args.task)
+        cfg.policy.flow_matcher.name = "conditional"     # identity pairing for timing; the OT draw is host work
+        S = cfg.task.state_dim
+        stats = {cfg.task.state_key: {"mean": [0.0] * S, "std": [1.0] * S}, cfg.task.action_key: {"mean": [0.0] * A, "std": [1.0] * A}}
+        torch.manual_seed(0)
+        pol = VitaPolicy(cfg, stats)
+        pol.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100000)
+        TB = args.train_batch
+        gt = torch.Generator().manual_seed(100 + rank)
+        ncam = len(cfg.task.image_keys)
+        tbatch = {cfg.task.state_key: torch.randn(TB, 1, S, generator=gt).to(dev),
+                  "observation.features": torch.relu(torch.randn(TB, 1, 512 * ncam, generator=gt)).to(dev),
+                  cfg.task.action_key: torch.randn(TB, 16, A, generator=gt).to(dev)}
+        tts = torch.rand(64, TB, generator=gt).to(dev)
+        tr.step_counter = 1000                           # past the lr warm-up, so the update is not a no-op
+        for i in range(3):
+            tr.train_step(tbatch, t=tts[i % 64])
+        fence()
+        nts = args.train_steps or args.steps
+        t0 = time.perf_counter()
+        for i in range(nts):
+            tr.train_step(tbatch, t=tts[i % 64])
+        fence()
+        tel = time.perf_counter() - t0
+        if dist is not None:
+            tt = torch.tensor([tel], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tel = tt.item()
+        m = tr.metrics()
+        f_train = 3 * (2 * obs_dim * fw.D + 19_734_528 + (2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D + 7_864_320)
+                       + K * (2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D)
+                       + 2 * (2 * fw.D * dw.HD + dw.w.NL * 4 * dw.HD * dw.HD + 2 * dw.HD * dw.OUT)) if args.task == "hook_package" else None
+        train = {"metric": "train samples/sec", "value": round(world * TB * nts / tel, 1), "unit": "samples/s",
+                 "ms_per_step": round(tel * 1e3 / nts, 4), "steps": nts, "batch_per_gpu": TB, "global_batch": TB * world,
+                 "dtype": "f32", "loss": round(m["loss"], 6), "grad_norm": round(m["grad_norm"], 6),
+                 "grad_bytes_allreduced_per_step": int(tr.flat_grad.numel() * 4) if world > 1 else 0,
+                 "parallelism": f"data-parallel x{world}, 3 event-driven gradient buckets over RCCL" if world > 1 else "single GPU",
+                 "includes": "normalize, fused forward+backward (1 FM eval + K Euler steps + encoder + 2 decodes), grad-norm clip, AdamW, EMA; observer excluded (camera latents are the input)",
+                 "algorithmic_flops_per_sample_fwd_bwd": f_train}
+        if f_train:
+            train["tflops"] = round(train["value"] * f_train / 1e12 / world, 2)
+            train["frac_of_f32_mfma_peak"] = round(train["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+        del tr, pol
 
     # ---- per-kernel roofline: HIP events around the dominant GEMM classes, on the launch stream
     def time_linear(M, N, Kd, reps=20, **kw):
@@ -199,6 +253,7 @@ def main():
                          "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic,
                          "flops_per_launch": 2.0 * B * fw.FF * fw.H},
             "kernels": kernels,
+            "train": train,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)
