@@ -5,6 +5,9 @@
 #include <stdlib.h>
 #include <vector>
 #include "../include/vita_hip.h"
+#ifdef VITA_STAMP
+extern "C" int vita_lab_read_stamps(unsigned long long*, int);
+#endif
 
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
@@ -42,6 +45,25 @@ int main(int argc, char** argv) {
     CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
+#ifdef VITA_STAMP
+    {
+        int tiles = ((M + 127) / 128) * ((N + 127) / 128);
+        if (tiles < 512) tiles = ((M + 63) / 64) * ((N + 127) / 128);
+        if (tiles > 4096) tiles = 4096;
+        std::vector<unsigned long long> st(tiles * 8);
+        CK(hipDeviceSynchronize());
+        vita_lab_read_stamps(st.data(), tiles * 8);
+        double pro = 0, loop = 0, epi = 0, clk = 0; unsigned long long t0 = ~0ull, t3 = 0, r0 = ~0ull, r1 = 0;
+        for (int i = 0; i < tiles; ++i) {
+            pro += st[i * 8 + 1] - st[i * 8]; loop += st[i * 8 + 2] - st[i * 8 + 1]; epi += st[i * 8 + 3] - st[i * 8 + 2];
+            if (st[i * 8] < t0) t0 = st[i * 8]; if (st[i * 8 + 3] > t3) t3 = st[i * 8 + 3];
+            clk += (double)(st[i * 8 + 3] - st[i * 8]) / (double)(st[i * 8 + 5] - st[i * 8 + 4]) * 0.1;   // GHz
+            if (st[i * 8 + 4] < r0) r0 = st[i * 8 + 4]; if (st[i * 8 + 5] > r1) r1 = st[i * 8 + 5];
+        }
+        printf("stamps (shader cycles) tiles=%d prologue=%.0f loop=%.0f epilogue=%.0f | in-kernel clock %.3f GHz | last launch first-WG-start..last-WG-end %.2f us\n",
+               tiles, pro / tiles, loop / tiles, epi / tiles, clk / tiles, (r1 - r0) * 0.01);
+    }
+#endif
     printf("padx=%d padw=%d ", padx, padw);
     printf("M=%d N=%d K=%d ln=%d act=%d gated=%d : %.2f us  %.2f TFLOP/s  %.1f%% of 157.3\n", M, N, K, ln, act, gated, us, tf, tf / 157.3 * 100);
     return 0;

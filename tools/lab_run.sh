@@ -1,7 +1,8 @@
 #!/bin/bash
-for v in 0 "$@"; do
-  if [ $v = 0 ]; then L=vita_amd; else L=tools/lab/v$v; fi
-  echo "== variant $v"
-  LD_LIBRARY_PATH=$L timeout -k 5 60 tools/bench_gemm 64 128 2048 0 0 1 50
-  LD_LIBRARY_PATH=$L timeout -k 5 60 tools/bench_gemm 4096 512 2048 0 0 1 50
+# usage: tools/lab_run.sh <variant dirs under tools/lab ...>  — the hook_package B=4096 GEMM shapes on each variant
+for v in "$@"; do
+  echo "== $v"
+  for a in "4096 2048 512 0 3 0" "4096 512 2048 0 0 1" "4096 512 512 0 0 0" "4096 336 512 0 0 0" "4096 2048 512 1 3 0"; do
+    timeout -k 5 60 tools/lab/$v/bench_gemm $a 30 || exit 1
+  done
 done

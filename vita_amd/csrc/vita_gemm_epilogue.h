@@ -1,0 +1,138 @@
+// Shared GEMM epilogue: accumulators -> LDS (transposed to row-major) -> 16-byte coalesced global stores.
+//
+// A 32x32 MFMA accumulator gives a lane ONE column and 16 rows, so storing from registers means 4-byte
+// stores of 128-byte row segments: measured 16.7k cycles for a 128x128 fp32 tile (store-issue bound,
+// ~4 B/clk/CU), 18 % of the tile's time.  The stage buffers are dead once the k-loop ends, so the tile
+// is bounced through them: each wave writes its accumulators (ds_write_b32, conflict-free), and after one
+// barrier every thread reads float4s of whole rows (ds_read_b128, conflict-free with the +4 pad) and issues
+// global_store_dwordx4 covering 512 contiguous bytes per row.  Bias / activation / gate / residual /
+// pre-activation output / activation-derivative input are applied on the float4 side, with 16-byte loads.
+//
+//   z = acc + bias ; [preact = z] ; v = act_grad_z ? z * act'(zin) : act(z) ; v *= gate ; v = resid + v ; Y = v
+#pragma once
+#include <type_traits>
+
+#include "vita_common.h"
+
+namespace vita {
+
+struct EpiParams {
+    float* Y; int64_t ldy;
+    int M, N;
+    const float* bias;
+    int act;
+    const float* gate; int64_t ld_gate;       // vector (ld 0) or matrix
+    int use_gate_scalar; float gate_scalar;
+    const float* resid; int64_t ld_resid;
+    float* preact; int64_t ld_preact;
+    const float* act_grad_z; int64_t ld_act_grad_z;
+    int vec;                                    // every pointer 16-byte aligned, every stride a multiple of 4
+};
+
+inline bool epi_aligned(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
+inline int epi_vec_ok(const EpiParams& e) {
+    auto ok = [](const void* q, int64_t ld) { return q == nullptr || (epi_aligned(q) && ld % 4 == 0); };
+    return ok(e.Y, e.ldy) && ok(e.bias, 0) && ok(e.gate, e.ld_gate) && ok(e.resid, e.ld_resid) && ok(e.preact, e.ld_preact) &&
+           ok(e.act_grad_z, e.ld_act_grad_z);
+}
+
+template <int ACT, bool BWD>
+__device__ __forceinline__ float epi_elem(float acc, float bias, float zin, float g, bool has_gate, float r, bool has_resid, float* pre) {
+    const float z = acc + bias;
+    if (pre) *pre = z;
+    float v;
+    if constexpr (BWD) v = z * act_grad(zin, ACT);
+    else v = apply_act_t<ACT>(z);
+    if (has_gate) v = v * g;
+    if (has_resid) v = r + v;
+    return v;
+}
+
+// obuf: at least BM * (BN + 4) floats of LDS that no wave reads any more (caller barriers before the call).
+template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD>
+__device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
+                                              int lane, int tid) {
+    constexpr int S = BN + 4;
+    constexpr int TM = BM / 2, TN = BN / 4;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int col = wn * TN + j * 32 + (lane & 31);
+                obuf[row * S + col] = acc[i][j][r];
+            }
+    __syncthreads();
+    const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
+    const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
+    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
+    const bool has_resid = e.resid != nullptr;
+    constexpr int C4 = BN / 4;
+    constexpr int ITERS = BM * C4 / NT_;
+    static_assert(BM * C4 % NT_ == 0, "tile / thread-count mismatch");
+#pragma unroll 4
+    for (int it = 0; it < ITERS; ++it) {
+        const int c = tid + it * NT_;
+        const int lr = c / C4, lc = (c % C4) * 4;
+        const int row = m0 + lr, col = n0 + lc;
+        if (row >= e.M || col >= e.N) continue;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(obuf + lr * S + lc);
+        if (e.vec && col + 3 < e.N) {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f}, zin = b, g = b, rs = b, pre, out;
+            if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
+            if constexpr (BWD) zin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+            if (gate_vec) g = *reinterpret_cast<const f32x4*>(e.gate + col);
+            else if (gate_mat) g = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
+            else g = f32x4{e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
+            if (has_resid) rs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float p_ = 0.f;
+                out[k] = epi_elem<ACT, BWD>(a[k], b[k], zin[k], g[k], has_gate, rs[k], has_resid, e.preact ? &p_ : nullptr);
+                pre[k] = p_;
+            }
+            if (e.preact) *reinterpret_cast<f32x4*>(e.preact + (int64_t)row * e.ld_preact + col) = pre;
+            *reinterpret_cast<f32x4*>(e.Y + (int64_t)row * e.ldy + col) = out;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int cc = col + k;
+                if (cc >= e.N) break;
+                const float b = e.bias ? e.bias[cc] : 0.f;
+                float zin = 0.f;
+                if constexpr (BWD) zin = e.act_grad_z[(int64_t)row * e.ld_act_grad_z + cc];
+                const float g = gate_vec ? e.gate[cc] : (gate_mat ? e.gate[(int64_t)row * e.ld_gate + cc] : e.gate_scalar);
+                const float rs = has_resid ? e.resid[(int64_t)row * e.ld_resid + cc] : 0.f;
+                float p_ = 0.f;
+                const float v = epi_elem<ACT, BWD>(a[k], b, zin, g, has_gate, rs, has_resid, e.preact ? &p_ : nullptr);
+                if (e.preact) e.preact[(int64_t)row * e.ld_preact + cc] = p_;
+                e.Y[(int64_t)row * e.ldy + cc] = v;
+            }
+        }
+    }
+}
+
+// run-time activation -> compile-time dispatch.  BACKWARD = false: forward GEMMs (act = the activation applied);
+// BACKWARD = true: the transposed-operand GEMMs (act = the activation whose derivative is applied from act_grad_z).
+template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD>
+__device__ __forceinline__ void epilogue_dispatch(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
+                                                  int lane, int tid) {
+#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD>(acc, obuf, e, m0, n0, wm, wn, lane, tid)
+    if (BACKWARD && e.act_grad_z == nullptr) {
+        epilogue_tile<BM, BN, MI, NI, NT_, VITA_ACT_NONE, false>(acc, obuf, e, m0, n0, wm, wn, lane, tid);
+        return;
+    }
+    switch (e.act) {
+        case VITA_ACT_RELU: VITA_EPI(VITA_ACT_RELU); break;
+        case VITA_ACT_GELU_ERF: VITA_EPI(VITA_ACT_GELU_ERF); break;
+        case VITA_ACT_GELU_TANH: VITA_EPI(VITA_ACT_GELU_TANH); break;
+        case VITA_ACT_SILU: VITA_EPI(VITA_ACT_SILU); break;
+        case VITA_ACT_MISH: VITA_EPI(VITA_ACT_MISH); break;
+        default: VITA_EPI(VITA_ACT_NONE); break;
+    }
+#undef VITA_EPI
+}
+
+}  // namespace vita

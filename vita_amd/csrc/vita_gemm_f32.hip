@@ -18,7 +18,7 @@
 //   8c+4+j in one 32x32x2 MFMA: 4 MFMAs per pair of 16-byte LDS reads.
 #include <type_traits>
 
-#include "vita_common.h"
+#include "vita_gemm_epilogue.h"
 
 namespace vita {
 
@@ -38,6 +38,7 @@ struct GemmParams {
     float* preact; int64_t ld_preact;
     int tiles_m, tiles_n;
     int vec_x, vec_w, vec_p;  // 16-byte vector loads legal for X / W / pro vectors
+    EpiParams epi;
 };
 
 constexpr int NT = 512;
@@ -271,47 +272,8 @@ __global__ __launch_bounds__(NT) void gemm_f32_kernel(GemmParams p) {
         buf = buf1;
     }
 
-    // ---- epilogue: bias, activation, gate, residual --------------------------------------
-    auto epilogue = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-        const bool gate_vec = (p.gate != nullptr) && (p.ld_gate == 0);
-        const bool gate_mat = (p.gate != nullptr) && (p.ld_gate != 0);
-        const bool has_gate = p.use_gate_scalar || (p.gate != nullptr);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int col = n0 + wn * TN + j * 32 + (lane & 31);
-            const bool col_ok = col < p.N;
-            const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-            float gcol = p.use_gate_scalar ? p.gate_scalar : 1.0f;
-            if (gate_vec && col_ok) gcol = p.gate[col];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < p.M && col_ok) {
-                        const float z = acc[i][j][r] + bias;
-                        if (p.preact != nullptr) p.preact[(int64_t)row * p.ld_preact + col] = z;
-                        float v = apply_act_t<ACT>(z);
-                        if (has_gate) {
-                            const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
-                            v = v * g;
-                        }
-                        if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
-                        p.Y[(int64_t)row * p.ldy + col] = v;
-                    }
-                }
-            }
-        }
-    };
-    switch (p.act) {
-        case VITA_ACT_RELU: epilogue(std::integral_constant<int, VITA_ACT_RELU>{}); break;
-        case VITA_ACT_GELU_ERF: epilogue(std::integral_constant<int, VITA_ACT_GELU_ERF>{}); break;
-        case VITA_ACT_GELU_TANH: epilogue(std::integral_constant<int, VITA_ACT_GELU_TANH>{}); break;
-        case VITA_ACT_SILU: epilogue(std::integral_constant<int, VITA_ACT_SILU>{}); break;
-        case VITA_ACT_MISH: epilogue(std::integral_constant<int, VITA_ACT_MISH>{}); break;
-        default: epilogue(std::integral_constant<int, VITA_ACT_NONE>{}); break;
-    }
+    // ---- epilogue: through the (now dead) staging buffers, see vita_gemm_epilogue.h (the k-loop ended on a barrier)
+    epilogue_dispatch<BM, BN, MI, NI, NT, false>(acc, smem, p.epi, m0, n0, wm, wn, lane, tid);
 }
 
 template <int BM, int BN, int BK>
@@ -374,6 +336,12 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
     p.resid = a.resid; p.ld_resid = a.ld_resid;
     p.preact = a.preact; p.ld_preact = a.ld_preact;
+    p.epi.Y = a.Y; p.epi.ldy = a.ldy; p.epi.M = a.M; p.epi.N = a.N; p.epi.bias = a.bias; p.epi.act = a.act;
+    p.epi.gate = a.gate; p.epi.ld_gate = a.ld_gate; p.epi.use_gate_scalar = a.use_gate_scalar;
+    p.epi.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
+    p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
+    p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
+    p.epi.vec = epi_vec_ok(p.epi);
     p.vec_x = (a.K % 4 == 0) && (a.ldx % 4 == 0) && aligned16(a.X);
     p.vec_w = (a.K % 4 == 0) && (a.ldw % 4 == 0) && aligned16(a.W);
     p.vec_p = (a.pro != VITA_PRO_NONE) && (a.K % 4 == 0) && (a.ld_pro_mul % 4 == 0) && (a.ld_pro_add % 4 == 0) &&

@@ -24,7 +24,7 @@
 //                 that hides under the 64-cycle fp32 MFMAs.
 #include <type_traits>
 
-#include "vita_common.h"
+#include "vita_gemm_epilogue.h"
 
 namespace vita {
 
@@ -45,11 +45,34 @@ struct GemmParamsDma {
     const float* resid; int64_t ld_resid;
     float* preact; int64_t ld_preact;
     int tiles_m, tiles_n;
+    EpiParams epi;
 };
 
 constexpr int DNT = 512;
 
 __device__ __attribute__((aligned(16))) float g_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
+
+#ifdef VITA_STAMP
+// Diagnostic build only (tools/lab_variant.sh): per-workgroup s_memtime stamps, read back by vita_lab_read_stamps.
+__device__ unsigned long long g_stamps[4096 * 8];
+#define STAMP(i)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t__;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t__;          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#define RSTAMP(i)                                                                                 \
+    do {                                                                                          \
+        unsigned long long t__;                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t__;          \
+    } while (0)
+#else
+#define STAMP(i)
+#define RSTAMP(i)
+#endif
 
 __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -69,8 +92,9 @@ __device__ __forceinline__ int swz(int r) {
     else return r & 15;
 }
 
-template <int BM, int BN, int BK, int NS, bool LN>
-__global__ __launch_bounds__(DNT) void gemm_f32_dma_kernel(GemmParamsDma p) {
+// OCC = waves per SIMD the register allocation must allow (2 = one 512-thread workgroup per CU, 4 = two)
+template <int BM, int BN, int BK, int NS, bool LN, int OCC>
+__global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p) {
     constexpr int CH = BK / 4;                 // 16-byte chunks per tile row
     constexpr int RPI = 64 / CH;               // rows covered by one DMA wave-instruction
     constexpr int A_DMA = BM / RPI / 8;        // DMA instructions per wave per tile (A)
@@ -88,6 +112,14 @@ __global__ __launch_bounds__(DNT) void gemm_f32_dma_kernel(GemmParamsDma p) {
     float* lna = lnm + (LN ? p.K : 0);
     float* stat = lna + (LN ? p.K : 0);
 
+#ifdef VITA_STAGGER   // lab: delay half of the workgroups so co-resident pairs are out of phase
+    if ((blockIdx.x >> VITA_STAGGER_SHIFT) & 1) {
+#pragma unroll 1
+        for (int i = 0; i < VITA_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
+    RSTAMP(4);
+    STAMP(0);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -273,6 +305,7 @@ __global__ __launch_bounds__(DNT) void gemm_f32_dma_kernel(GemmParamsDma p) {
         }
     }
     read_frags(0, 0, 0, af[0], bf[0], lm[0], la[0]);
+    STAMP(1);
 
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
@@ -306,52 +339,17 @@ __global__ __launch_bounds__(DNT) void gemm_f32_dma_kernel(GemmParamsDma p) {
         // the reads of tile kt must have retired, and they fed the MFMAs above.
         stage = stage1;
     }
+    STAMP(2);
     wait_vmcnt<0>();  // drain the dummy tail DMAs before the wave exits / LDS is released
 
-    // ---- epilogue: bias, activation, gate, residual --------------------------------------
-    auto epilogue = [&](auto act_tag) {
-        constexpr int ACT = decltype(act_tag)::value;
-        const bool gate_vec = (p.gate != nullptr) && (p.ld_gate == 0);
-        const bool gate_mat = (p.gate != nullptr) && (p.ld_gate != 0);
-        const bool has_gate = p.use_gate_scalar || (p.gate != nullptr);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int col = n0 + wn * TN + j * 32 + (lane & 31);
-            const bool col_ok = col < p.N;
-            const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-            float gcol = p.use_gate_scalar ? p.gate_scalar : 1.0f;
-            if (gate_vec && col_ok) gcol = p.gate[col];
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                    if (row < p.M && col_ok) {
-                        const float z = acc[i][j][r] + bias;
-                        if (p.preact != nullptr) p.preact[(int64_t)row * p.ld_preact + col] = z;
-                        float v = apply_act_t<ACT>(z);
-                        if (has_gate) {
-                            const float g = gate_mat ? p.gate[(int64_t)row * p.ld_gate + col] : gcol;
-                            v = v * g;
-                        }
-                        if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
-                        p.Y[(int64_t)row * p.ldy + col] = v;
-                    }
-                }
-            }
-        }
-    };
-    switch (p.act) {
-        case VITA_ACT_RELU: epilogue(std::integral_constant<int, VITA_ACT_RELU>{}); break;
-        case VITA_ACT_GELU_ERF: epilogue(std::integral_constant<int, VITA_ACT_GELU_ERF>{}); break;
-        case VITA_ACT_GELU_TANH: epilogue(std::integral_constant<int, VITA_ACT_GELU_TANH>{}); break;
-        case VITA_ACT_SILU: epilogue(std::integral_constant<int, VITA_ACT_SILU>{}); break;
-        case VITA_ACT_MISH: epilogue(std::integral_constant<int, VITA_ACT_MISH>{}); break;
-        default: epilogue(std::integral_constant<int, VITA_ACT_NONE>{}); break;
-    }
+    // ---- epilogue: through the (now dead) stage buffers, see vita_gemm_epilogue.h ------------
+    __syncthreads();   // every wave is done reading fragments, every DMA has landed
+    epilogue_dispatch<BM, BN, MI, NI, DNT, false>(acc, smem, p.epi, m0, n0, wm, wn, lane, tid);
+    STAMP(3);
+    RSTAMP(5);
 }
 
-template <int BM, int BN, int BK, int NS>
+template <int BM, int BN, int BK, int NS, int OCC = 2>
 static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     GemmParamsDma p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -359,8 +357,8 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     const bool ln = p.pro != VITA_PRO_NONE;
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0)) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(DNT);
-    if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false>), grid, block, lds, stream, p);
+    if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC>), grid, block, lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
@@ -377,6 +375,12 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
     p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
     p.resid = a.resid; p.ld_resid = a.ld_resid;
     p.preact = a.preact; p.ld_preact = a.ld_preact;
+    p.epi.Y = a.Y; p.epi.ldy = a.ldy; p.epi.M = a.M; p.epi.N = a.N; p.epi.bias = a.bias; p.epi.act = a.act;
+    p.epi.gate = a.gate; p.epi.ld_gate = a.ld_gate; p.epi.use_gate_scalar = a.use_gate_scalar;
+    p.epi.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
+    p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
+    p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
+    p.epi.vec = epi_vec_ok(p.epi);
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
 #ifndef VITA_DMA_CFG
 #define VITA_DMA_CFG 0
@@ -384,14 +388,14 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
 #if VITA_DMA_CFG == 0
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 32, 4>(p, stream);
-#elif VITA_DMA_CFG == 1
+#elif VITA_DMA_CFG == 1   // two co-resident workgroups per CU everywhere (72 KB LDS each)
+    return launch_dma<64, 128, 32, 3, 4>(p, stream);
+#elif VITA_DMA_CFG == 2   // two per CU only for the small-N GEMMs
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
-    return launch_dma<64, 128, 64, 3>(p, stream);
-#elif VITA_DMA_CFG == 2
-    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
-    return launch_dma<64, 128, 32, 6>(p, stream);
+    return launch_dma<64, 128, 32, 3, 4>(p, stream);
 #else
-    return launch_dma<64, 128, 64, 3>(p, stream);
+    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
+    return launch_dma<64, 128, 32, 3>(p, stream);
 #endif
 }
 
@@ -407,3 +411,9 @@ bool gemm_f32_dma_eligible(const vita_linear_args& a) {
 }
 
 }  // namespace vita
+
+#ifdef VITA_STAMP
+extern "C" int vita_lab_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vita::g_stamps), sizeof(unsigned long long) * n, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -14,7 +14,7 @@
 // conflict-free) with the same k pairing (8c + 4h + j) the row operand's ds_read_b128 gives.
 #include <type_traits>
 
-#include "vita_common.h"
+#include "vita_gemm_epilogue.h"
 
 namespace vita {
 
@@ -28,6 +28,7 @@ struct GemmParamsT {
     const float* resid; int64_t ld_resid;
     const float* act_grad_z; int64_t ld_act_grad_z; int act;   // epilogue: *= act'(z[row,col])
     int tiles_m, tiles_n;
+    EpiParams epi;
 };
 
 constexpr int TNT = 512;
@@ -186,25 +187,8 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
         buf = buf1;
     }
 
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int col = n0 + wn * TN + j * 32 + (lane & 31);
-        const bool col_ok = col < p.N;
-        const float bias = (p.bias != nullptr && col_ok) ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < p.M && col_ok) {
-                    float v = acc[i][j][r] + bias;
-                    if (p.act_grad_z != nullptr) v = v * act_grad(p.act_grad_z[(int64_t)row * p.ld_act_grad_z + col], p.act);
-                    if (p.use_gate_scalar) v = v * p.gate_scalar;
-                    if (p.resid != nullptr) v = p.resid[(int64_t)row * p.ld_resid + col] + v;
-                    p.Y[(int64_t)row * p.ldy + col] = v;
-                }
-            }
-    }
+    // the k-loop ended on a barrier: the staging buffers are dead (vita_gemm_epilogue.h)
+    epilogue_dispatch<BM, BN, MI, NI, TNT, true>(acc, smem, p.epi, m0, n0, wm, wn, lane, tid);
 }
 
 template <bool ACOL, bool BCOL>
@@ -243,6 +227,12 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream) {
     p.use_gate_scalar = a.use_gate_scalar; p.gate_scalar = a.gate_scalar;
     p.resid = a.resid; p.ld_resid = a.ld_resid;
     p.act_grad_z = a.act_grad_z; p.ld_act_grad_z = a.ld_act_grad_z; p.act = a.act;
+    p.epi.Y = a.Y; p.epi.ldy = a.ldy; p.epi.M = a.M; p.epi.N = a.N; p.epi.bias = a.bias; p.epi.act = a.act;
+    p.epi.gate = a.gate; p.epi.ld_gate = a.ld_gate; p.epi.use_gate_scalar = a.use_gate_scalar;
+    p.epi.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
+    p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
+    p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
+    p.epi.vec = epi_vec_ok(p.epi);
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool vx = al(a.X) && a.ldx % 4 == 0 && (a.a_col ? a.M % 4 == 0 : a.K % 4 == 0);
     const bool vw = al(a.W) && a.ldw % 4 == 0 && (a.b_col ? a.N % 4 == 0 : a.K % 4 == 0);
