@@ -91,9 +91,15 @@ typedef struct vita_linear_args {
     /* with a_col/b_col only: the result is multiplied by act'(act_grad_z[m,n]) — the backward of the activation that
      * followed the previous layer, fused into this layer's dgrad (`act` names the activation).  Y may alias act_grad_z. */
     const float* act_grad_z; int64_t ld_act_grad_z;
+    /* optional scratch for split-K (NULL = never split).  With few output tiles and a long reduction (M <= ~512 rows:
+     * serving batches, per-GPU training batches) the k range is cut across workgroups; the partial tiles are summed in a
+     * fixed order by a second kernel that applies the epilogue, so results stay bitwise reproducible for a given shape.
+     * vita_splitk_workspace_bytes() is always enough; 256-byte aligned. */
+    void* splitk_ws; size_t splitk_ws_bytes;
 } vita_linear_args;
 
 int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream);
+size_t vita_splitk_workspace_bytes(void);
 
 /* ---------------------------------------------------------------------------------------
  * Weight descriptors: device pointers to the checkpoint tensors, unchanged.

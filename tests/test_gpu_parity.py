@@ -168,6 +168,26 @@ def test_linear_ln_affine_and_euler_epilogue(ops, dev):
     close(y, ref, 2e-6, "ln_affine + euler")
 
 
+@pytest.mark.parametrize("M,N,K", [(25, 512, 2048), (128, 2048, 512), (128, 512, 2048), (1, 336, 512), (300, 512, 520), (64, 130, 4096)])
+def test_linear_split_k_small_batches(ops, dev, M, N, K):
+    """Serving / per-GPU training batch sizes: few output tiles and a long reduction take the split-K path (partials summed
+    in a fixed order by a second kernel that applies the epilogue)."""
+    from vita_amd import _lib as L
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    gamma = torch.randn(N, generator=g)
+    r = torch.randn(M, N, generator=g)
+    z = torch.nn.functional.linear(x.double(), w.double(), b.double())
+    ref = r.double() + torch.nn.functional.gelu(z, approximate="tanh") * gamma.double()
+    rd = r.to(dev)
+    y = ops.linear(x.to(dev), w.to(dev), b.to(dev), L.ACT_GELU_TANH, gate=gamma.to(dev), resid=rd, out=rd)   # in place on the residual
+    close(y, ref, 3e-6, "split-K fused epilogue")
+    y2 = ops.linear(x.to(dev), w.to(dev), b.to(dev), L.ACT_GELU_TANH, gate=gamma.to(dev), resid=r.to(dev))
+    assert torch.equal(y, y2), "split-K result not reproducible"
+
+
 def test_linear_rejects_bad_arguments(ops, dev):
     from vita_amd._lib import VitaHipError
     x = torch.zeros(4, 8, device=dev)
@@ -250,9 +270,13 @@ def test_full_size_hook_package_b4096(ops, dev):
     idx = torch.cat([torch.arange(0, 8), torch.arange(2040, 2056), torch.arange(4088, 4096)])
     ref = O.generate_actions(sd, obs[idx], K, 16, A).reshape(len(idx), -1)
     close(acts[idx.to(dev)], ref, TOL, "B=4096 sample rows")
-    # (2) row independence / tiling invariance: any sub-batch gives bitwise the same rows
-    sub = ops.generate_actions(ow, ob, fw, dw, obs[1000:1100].to(dev), K)
-    assert torch.equal(sub, acts[1000:1100]), "rows depend on their position in the batch"
+    # (2) row independence / tiling invariance: a sub-batch on the same kernel path gives bitwise the same rows; a small
+    #     one (which takes the split-K path: different summation order) agrees to fp32 rounding
+    sub = ops.generate_actions(ow, ob, fw, dw, obs[1000:4000].to(dev), K)
+    assert torch.equal(sub, acts[1000:4000]), "rows depend on their position in the batch"
+    small = ops.generate_actions(ow, ob, fw, dw, obs[1000:1100].to(dev), K)
+    close(small, acts[1000:1100], 2e-6, "small sub-batch (split-K path)")
+    assert torch.equal(small, ops.generate_actions(ow, ob, fw, dw, obs[1000:1100].to(dev), K)), "split-K path not deterministic"
     # (3) determinism
     again = ops.generate_actions(ow, ob, fw, dw, obs.to(dev), K)
     assert torch.equal(again, acts)

@@ -34,6 +34,7 @@ class LinearArgs(C.Structure):
         ("preact", c_fp), ("ld_preact", C.c_int64),
         ("a_col", C.c_int32), ("b_col", C.c_int32),
         ("act_grad_z", c_fp), ("ld_act_grad_z", C.c_int64),
+        ("splitk_ws", c_fp), ("splitk_ws_bytes", C.c_size_t),
     ]
 
 
@@ -98,6 +99,7 @@ SIGNATURES = {
     "vita_abi_version": (C.c_int, []),
     "vita_last_error": (C.c_char_p, []),
     "vita_linear_f32": (C.c_int, [C.POINTER(LinearArgs), c_fp]),
+    "vita_splitk_workspace_bytes": (C.c_size_t, []),
     "vita_flownet_forward_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.c_int32]),
     "vita_flownet_forward_f32": (C.c_int, [C.POINTER(FlowNetWeights), c_fp, C.c_int64, c_fp, c_fp, C.c_int64,
                                            C.c_int32, c_fp, C.c_size_t, c_fp]),

@@ -19,13 +19,14 @@ void set_error(const char* fmt, ...) {
 }
 
 struct FlowWs {
-    float *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
+    float *sk, *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
     size_t bytes;
 };
 // T = number of distinct timesteps (num_steps when sampling, B for per-row t)
 static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, bool need_x) {
     Carver c(ws);
     FlowWs f;
+    f.sk = c.take(kSplitkBytes / sizeof(float));
     f.ts = c.take((size_t)T);
     f.sin = c.take((size_t)T * w->TE);
     f.hid = c.take((size_t)T * 4 * w->TE);
@@ -111,6 +112,7 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
                       float* traj, void* ws, hipStream_t s) {
     const int D = w->D, H = w->H, L = w->L;
     FlowWs f = carve_flow(ws, w, B, K, false);
+    SplitkScope sk(f.sk, kSplitkBytes);
     VITA_TRY(launch_step_times(f.ts, K, s));
     VITA_TRY(time_path(w, f, K, s));
     const float dt = (float)(1.0 / (double)K);  // python float 1.0/num_steps, rounded to fp32 at the multiply
@@ -131,10 +133,11 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
     return VITA_OK;
 }
 
-struct DecWs { float *a, *b; size_t bytes; };
+struct DecWs { float *sk, *a, *b; size_t bytes; };
 static DecWs carve_dec(void* ws, const vita_decoder_weights* w, int B) {
     Carver c(ws);
     DecWs d;
+    d.sk = c.take(kSplitkBytes / sizeof(float));
     d.a = c.take((size_t)B * w->HD);
     d.b = c.take((size_t)B * w->HD);
     d.bytes = c.off;
@@ -152,6 +155,7 @@ static int decoder_forward(const vita_decoder_weights* w, const float* z, int64_
                            hipStream_t s) {
     const int D = w->D, HD = w->HD;
     DecWs d = carve_dec(ws, w, B);
+    SplitkScope sk(d.sk, kSplitkBytes);
     VITA_TRY(gemm_f32(lin(z, ldz, w->in_w, D, w->in_b, d.a, HD, B, HD, D, VITA_ACT_NONE), s));           // action_ae.py:274
     for (int i = 0; i < w->NL; ++i) {                                                                     // :275-276
         VITA_TRY(gemm_f32(lin(d.a, HD, w->fc1_w[i], HD, w->fc1_b[i], d.b, HD, B, HD, HD, VITA_ACT_GELU_ERF), s));
@@ -169,6 +173,8 @@ extern "C" {
 
 int vita_abi_version(void) { return VITA_ABI_VERSION; }
 const char* vita_last_error(void) { return g_err; }
+
+size_t vita_splitk_workspace_bytes(void) { return size_t(32) << 20; }
 
 int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream) {
     VITA_REQUIRE(args != nullptr, "vita_linear_f32: null args");
@@ -189,6 +195,7 @@ int vita_flownet_forward_f32(const vita_flownet_weights* w, const float* x, int6
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_flownet_forward_workspace_bytes(w, B), "vita_flownet_forward_f32"));
     hipStream_t s = (hipStream_t)stream;
     FlowWs f = carve_flow(workspace, w, B, B, false);
+    SplitkScope sk(f.sk, kSplitkBytes);
     VITA_CHECK_HIP(hipMemcpyAsync(f.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     VITA_TRY(time_path(w, f, B, s));
     return flow_eval(w, f, x, ldx, f.mod, (int64_t)w->L * 3 * w->H, v, ldv, nullptr, 0, 0.f, B, s);
@@ -250,7 +257,10 @@ int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O,
     const int D = fw->D;
     float* lat = static_cast<float*>(workspace);
     char* rest = static_cast<char*>(workspace) + (((size_t)B * D * 4 + 255) & ~size_t(255));
-    VITA_TRY(gemm_f32(lin(obs_features, ldobs, obs_w, O, obs_b, lat, D, B, D, O, VITA_ACT_NONE), s));  // vita_policy.py:194
+    {
+        SplitkScope sk(rest, kSplitkBytes);   // the first kSplitkBytes of either carve below
+        VITA_TRY(gemm_f32(lin(obs_features, ldobs, obs_w, O, obs_b, lat, D, B, D, O, VITA_ACT_NONE), s));  // vita_policy.py:194
+    }
     VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s));                           // :196-203
     if (latents_out)
         VITA_CHECK_HIP(hipMemcpyAsync(latents_out, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s));

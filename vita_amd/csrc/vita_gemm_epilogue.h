@@ -27,6 +27,17 @@ struct EpiParams {
     float* preact; int64_t ld_preact;
     const float* act_grad_z; int64_t ld_act_grad_z;
     int vec;                                    // every pointer 16-byte aligned, every stride a multiple of 4
+    // split-K: when `partial` is set the tile's raw accumulators go to partial[(split*M + row)*ld_partial + col] and
+    // splitk_reduce_kernel applies the epilogue after summing the splits in a fixed order
+    float* partial; int64_t ld_partial;
+};
+
+// k-range of a split-K launch: blockIdx.x = split * tiles + tile; the split covers k in [split*k_per_split, ...)
+struct SplitK {
+    int splits = 1;
+    int k_per_split = 0;      // multiple of 128 (so of every kernel's BK)
+    float* partial = nullptr;
+    int64_t ld_partial = 0;
 };
 
 inline bool epi_aligned(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }
@@ -72,6 +83,17 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
     constexpr int C4 = BN / 4;
     constexpr int ITERS = BM * C4 / NT_;
     static_assert(BM * C4 % NT_ == 0, "tile / thread-count mismatch");
+    if (e.partial != nullptr) {   // split-K: raw accumulators only (ld_partial is a multiple of 4, the buffer 16-byte aligned)
+#pragma unroll 4
+        for (int it = 0; it < ITERS; ++it) {
+            const int c = tid + it * NT_;
+            const int lr = c / C4, lc = (c % C4) * 4;
+            const int row = m0 + lr, col = n0 + lc;
+            if (row >= e.M || col >= e.N) continue;
+            *reinterpret_cast<f32x4*>(e.partial + (int64_t)row * e.ld_partial + col) = *reinterpret_cast<const f32x4*>(obuf + lr * S + lc);
+        }
+        return;
+    }
 #pragma unroll 4
     for (int it = 0; it < ITERS; ++it) {
         const int c = tid + it * NT_;
@@ -120,7 +142,7 @@ template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD>
 __device__ __forceinline__ void epilogue_dispatch(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
                                                   int lane, int tid) {
 #define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD>(acc, obuf, e, m0, n0, wm, wn, lane, tid)
-    if (BACKWARD && e.act_grad_z == nullptr) {
+    if (e.partial != nullptr || (BACKWARD && e.act_grad_z == nullptr)) {
         epilogue_tile<BM, BN, MI, NI, NT_, VITA_ACT_NONE, false>(acc, obuf, e, m0, n0, wm, wn, lane, tid);
         return;
     }

@@ -22,6 +22,8 @@
 
 namespace vita {
 
+#define VITA_TRY_RC(expr) do { int rc__ = (expr); if (rc__ != VITA_OK) return rc__; } while (0)
+
 struct GemmParams {
     const float* X; int64_t ldx;
     const float* W; int64_t ldw;
@@ -297,14 +299,113 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream);
-int gemm_f32_t(const vita_linear_args& a, hipStream_t stream);
+int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
+int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 bool gemm_f32_dma_eligible(const vita_linear_args& a);
+
+// ---- split-K: second pass ------------------------------------------------------------------------
+// Y = epilogue( sum_{s=0..S-1} partial[s] ) with the splits added in index order (deterministic).
+constexpr size_t SPLITK_WS_BYTES = size_t(32) << 20;
+constexpr int SPLITK_MAX_TILES = 128;     // split only when a launch would fill at most half of the 256 CUs
+constexpr int SPLITK_MIN_K = 128;         // k elements per split (a multiple of every kernel's BK)
+
+template <int ACT, bool BWD>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(EpiParams e, const float* __restrict__ part, int64_t ldp, int S) {
+    const int c4 = (e.N + 3) / 4;
+    const int64_t n = (int64_t)e.M * c4, stride = (int64_t)gridDim.x * 256;
+    const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
+    const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
+    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
+    const bool has_resid = e.resid != nullptr;
+    const int64_t split_stride = (int64_t)e.M * ldp;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+        const int row = (int)(i / c4), col = (int)(i - (int64_t)row * c4) * 4;
+        const float* src = part + (int64_t)row * ldp + col;
+        f32x4 a = *reinterpret_cast<const f32x4*>(src);
+        for (int s2 = 1; s2 < S; ++s2) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(src + s2 * split_stride);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] = a[k] + b[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int cc = col + k;
+            if (cc >= e.N) break;
+            const float b = e.bias ? e.bias[cc] : 0.f;
+            float zin = 0.f;
+            if constexpr (BWD) zin = e.act_grad_z[(int64_t)row * e.ld_act_grad_z + cc];
+            const float g = gate_vec ? e.gate[cc] : (gate_mat ? e.gate[(int64_t)row * e.ld_gate + cc] : e.gate_scalar);
+            const float rs = has_resid ? e.resid[(int64_t)row * e.ld_resid + cc] : 0.f;
+            float p_ = 0.f;
+            const float v = epi_elem<ACT, BWD>(a[k], b, zin, g, has_gate, rs, has_resid, e.preact ? &p_ : nullptr);
+            if (e.preact) e.preact[(int64_t)row * e.ld_preact + cc] = p_;
+            e.Y[(int64_t)row * e.ldy + cc] = v;
+        }
+    }
+}
+
+static int launch_splitk_reduce(const EpiParams& e, const float* part, int64_t ldp, int S, hipStream_t stream) {
+    const int64_t n = (int64_t)e.M * ((e.N + 3) / 4);
+    int blocks = (int)((n + 255) / 256);
+    blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+#define VITA_RED(A, B) hipLaunchKernelGGL((splitk_reduce_kernel<A, B>), dim3(blocks), dim3(256), 0, stream, e, part, ldp, S)
+    const bool bwd = e.act_grad_z != nullptr;
+    switch (e.act) {
+        case VITA_ACT_RELU: if (bwd) VITA_RED(VITA_ACT_RELU, true); else VITA_RED(VITA_ACT_RELU, false); break;
+        case VITA_ACT_GELU_ERF: if (bwd) VITA_RED(VITA_ACT_GELU_ERF, true); else VITA_RED(VITA_ACT_GELU_ERF, false); break;
+        case VITA_ACT_GELU_TANH: if (bwd) VITA_RED(VITA_ACT_GELU_TANH, true); else VITA_RED(VITA_ACT_GELU_TANH, false); break;
+        case VITA_ACT_SILU: if (bwd) VITA_RED(VITA_ACT_SILU, true); else VITA_RED(VITA_ACT_SILU, false); break;
+        case VITA_ACT_MISH: if (bwd) VITA_RED(VITA_ACT_MISH, true); else VITA_RED(VITA_ACT_MISH, false); break;
+        default: VITA_RED(VITA_ACT_NONE, false); break;
+    }
+#undef VITA_RED
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+// Decide whether (and how far) to split the reduction of this call.  Returns splits == 1 for "do not".
+static SplitK plan_splitk(const vita_linear_args& a) {
+    SplitK sk;
+    if (a.splitk_ws == nullptr || (reinterpret_cast<uintptr_t>(a.splitk_ws) & 255u) != 0 || a.pro != VITA_PRO_NONE) return sk;
+    const long tiles = (long)((a.M + 63) / 64) * ((a.N + 127) / 128);
+    if (tiles > SPLITK_MAX_TILES || a.K < 2 * SPLITK_MIN_K) return sk;
+    long S = 256 / tiles;
+    const long by_k = a.K / SPLITK_MIN_K;
+    if (S > by_k) S = by_k;
+    const int64_t ldp = ((int64_t)a.N + 3) & ~int64_t(3);
+    const long by_ws = (long)(a.splitk_ws_bytes / ((size_t)a.M * ldp * sizeof(float)));
+    if (S > by_ws) S = by_ws;
+    if (S < 2) return sk;
+    int kps = (int)((a.K + S - 1) / S);
+    kps = (kps + SPLITK_MIN_K - 1) / SPLITK_MIN_K * SPLITK_MIN_K;
+    sk.splits = (a.K + kps - 1) / kps;       // every split is non-empty
+    sk.k_per_split = kps;
+    sk.partial = static_cast<float*>(a.splitk_ws);
+    sk.ld_partial = ldp;
+    if (sk.splits < 2) sk.splits = 1;
+    return sk;
+}
+
+static EpiParams epi_of(const vita_linear_args& a) {
+    EpiParams e{};
+    e.Y = a.Y; e.ldy = a.ldy; e.M = a.M; e.N = a.N; e.bias = a.bias; e.act = a.act;
+    e.gate = a.gate; e.ld_gate = a.ld_gate; e.use_gate_scalar = a.use_gate_scalar;
+    e.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
+    e.resid = a.resid; e.ld_resid = a.ld_resid; e.preact = a.preact; e.ld_preact = a.ld_preact;
+    e.act_grad_z = a.act_grad_z; e.ld_act_grad_z = a.ld_act_grad_z;
+    e.vec = 0;
+    return e;
+}
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     if (a.M == 0 && a.N > 0 && a.K > 0) return VITA_OK;  // empty batch: nothing to do (pointers may be null)
     VITA_REQUIRE(a.X && a.W && a.Y, "vita_linear_f32: X, W and Y must be non-null");
-    if (a.a_col || a.b_col) return gemm_f32_t(a, stream);
+    if (a.a_col || a.b_col) {
+        const SplitK sk = (a.M > 0 && a.K > 0) ? plan_splitk(a) : SplitK{};
+        VITA_TRY_RC(gemm_f32_t(a, stream, sk.splits > 1 ? &sk : nullptr));
+        if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
+        return VITA_OK;
+    }
     VITA_REQUIRE(a.M >= 0 && a.N > 0 && a.K > 0, "vita_linear_f32: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
     VITA_REQUIRE(a.preact == nullptr || a.ld_preact >= a.N, "vita_linear_f32: ld_preact must be >= N");
     VITA_REQUIRE(a.act_grad_z == nullptr, "vita_linear_f32: act_grad_z is a backward-pass (a_col/b_col) option");
@@ -322,9 +423,12 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "vita_linear_f32: ld_resid must be >= N");
     VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W,
                  "vita_linear_f32: Y must not alias X or W");
-#if !defined(VITA_LAB) || VITA_LAB != 7
-    if (gemm_f32_dma_eligible(a)) return gemm_f32_dma(a, stream);
-#endif
+    if (gemm_f32_dma_eligible(a)) {
+        const SplitK sk = plan_splitk(a);
+        VITA_TRY_RC(gemm_f32_dma(a, stream, sk.splits > 1 ? &sk : nullptr));
+        if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
+        return VITA_OK;
+    }
 
     GemmParams p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias;

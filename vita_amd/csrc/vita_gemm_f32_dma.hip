@@ -45,6 +45,7 @@ struct GemmParamsDma {
     const float* resid; int64_t ld_resid;
     float* preact; int64_t ld_preact;
     int tiles_m, tiles_n;
+    int sk_splits, sk_k;   // split-K: number of splits, k elements per split
     EpiParams epi;
 };
 
@@ -126,15 +127,17 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     const int wm = wave >> 2, wn = wave & 3;
 
     const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
+    const int split = p.sk_splits > 1 ? (int)blockIdx.x / nwg : 0;
+    int bid = blockIdx.x - split * nwg;
     {
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int K = p.K;
-    const int nk = (K + BK - 1) / BK;
+    const int kbase = split * p.sk_k;                                   // this workgroup reduces k in [kbase, K)
+    const int K = p.sk_splits > 1 ? min(p.K, kbase + p.sk_k) : p.K;
+    const int nk = (K - kbase + BK - 1) / BK;
 
     // ---- per-lane DMA sources: lane l of instruction j writes row (j*8+wave)*RPI + l/CH,
     //      chunk position l%CH, so it must fetch chunk (l%CH) ^ swz(row) of that row
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     auto issue_tile = [&](int kt, int stage) {
         float* sa = smem + stage * STAGE;
         float* sb = sa + BM * BK;
-        const int kb = kt * BK;
+        const int kb = kbase + kt * BK;
 #pragma unroll
         for (int j = 0; j < A_DMA; ++j) {
             const float* g = (kb + a_k[j] < K) ? a_src[j] + kb : g_zero_chunk;
@@ -344,7 +347,9 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
 
     // ---- epilogue: through the (now dead) stage buffers, see vita_gemm_epilogue.h ------------
     __syncthreads();   // every wave is done reading fragments, every DMA has landed
-    epilogue_dispatch<BM, BN, MI, NI, DNT, false>(acc, smem, p.epi, m0, n0, wm, wn, lane, tid);
+    EpiParams e = p.epi;
+    if (e.partial != nullptr) e.partial += (int64_t)split * p.M * e.ld_partial;
+    epilogue_dispatch<BM, BN, MI, NI, DNT, false>(acc, smem, e, m0, n0, wm, wn, lane, tid);
     STAMP(3);
     RSTAMP(5);
 }
@@ -356,7 +361,7 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     p.tiles_n = (p.N + BN - 1) / BN;
     const bool ln = p.pro != VITA_PRO_NONE;
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0)) * sizeof(float);
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(DNT);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(DNT);
     if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC>), grid, block, lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
@@ -365,7 +370,7 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
 
 // Eligibility is decided by the caller (vita_gemm_f32.hip): 16-byte aligned X/W rows, K % 4 == 0,
 // LayerNorm vectors broadcast over rows (ld == 0) and K small enough for the LDS tables.
-int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
+int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) {
     GemmParamsDma p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias;
     p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K;
@@ -381,9 +386,10 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
     p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
     p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
     p.epi.vec = epi_vec_ok(p.epi);
+    if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
 #ifndef VITA_DMA_CFG
-#define VITA_DMA_CFG 0
+#define VITA_DMA_CFG 4
 #endif
 #if VITA_DMA_CFG == 0
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
@@ -393,9 +399,12 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream) {
 #elif VITA_DMA_CFG == 2   // two per CU only for the small-N GEMMs
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 32, 3, 4>(p, stream);
-#else
+#elif VITA_DMA_CFG == 3
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 32, 3>(p, stream);
+#else   // 4: deeper k-tiles for the 64-row tile (one barrier per 32 MFMAs per wave): fc2 95.4 -> 89.6 us
+    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
+    return launch_dma<64, 128, 64, 3>(p, stream);
 #endif
 }
 

@@ -28,6 +28,7 @@ struct GemmParamsT {
     const float* resid; int64_t ld_resid;
     const float* act_grad_z; int64_t ld_act_grad_z; int act;   // epilogue: *= act'(z[row,col])
     int tiles_m, tiles_n;
+    int sk_splits, sk_k;
     EpiParams epi;
 };
 
@@ -59,15 +60,17 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int nwg = p.tiles_m * p.tiles_n;
-    int bid = blockIdx.x;
+    const int split = p.sk_splits > 1 ? (int)blockIdx.x / nwg : 0;
+    int bid = blockIdx.x - split * nwg;
     {
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
     const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
-    const int K = p.K;
-    const int nk = (K + BK - 1) / BK;
+    const int kbase = split * p.sk_k;
+    const int K = p.sk_splits > 1 ? min(p.K, kbase + p.sk_k) : p.K;
+    const int nk = (K - kbase + BK - 1) / BK;
 
     // slot geometry: (r, c) = LDS row / float offset in the row
     auto slot_rc = [&](int s, int per_row, int& r, int& c) { r = s / per_row; c = (s % per_row) * 4; };
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
             slot_rc(tid + i * TNT, T::PER_ROW, r, c);
             f32x4 v;
             if constexpr (COL) {      // LDS row r = k, c = offset along the output dim
-                const int k = kt * BK + r, o = o0 + c;
+                const int k = kbase + kt * BK + r, o = o0 + c;
                 const float* src = base + (int64_t)k * ld + o;
                 if constexpr (VEC) {
                     v = *reinterpret_cast<const f32x4*>((k < K && o < lim) ? src : g_zero_t);
@@ -91,7 +94,7 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
                     for (int j = 0; j < 4; ++j) v[j] = *((k < K && o + j < lim) ? src + j : g_zero_t);
                 }
             } else {                  // LDS row r = output row, c = k offset
-                const int k = kt * BK + c;
+                const int k = kbase + kt * BK + c;
                 const float* src = base + (int64_t)min(o0 + r, lim - 1) * ld + k;
                 if constexpr (VEC) {
                     v = *reinterpret_cast<const f32x4*>(k < K ? src : g_zero_t);
@@ -188,7 +191,9 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
     }
 
     // the k-loop ended on a barrier: the staging buffers are dead (vita_gemm_epilogue.h)
-    epilogue_dispatch<BM, BN, MI, NI, TNT, true>(acc, smem, p.epi, m0, n0, wm, wn, lane, tid);
+    EpiParams e = p.epi;
+    if (e.partial != nullptr) e.partial += (int64_t)split * p.M * e.ld_partial;
+    epilogue_dispatch<BM, BN, MI, NI, TNT, true>(acc, smem, e, m0, n0, wm, wn, lane, tid);
 }
 
 template <bool ACOL, bool BCOL>
@@ -197,14 +202,14 @@ static int launch_t(GemmParamsT p, bool vec, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = (size_t)3 * (OpTile<BM, BK, ACOL>::BUF + OpTile<BN, BK, BCOL>::BUF) * sizeof(float);
-    dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(TNT);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(TNT);
     if (vec) hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, BK, ACOL, BCOL, true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_f32_t_kernel<BM, BN, BK, ACOL, BCOL, false>), grid, block, lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
 
-int gemm_f32_t(const vita_linear_args& a, hipStream_t stream) {
+int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) {
     const char* who = "vita_linear_f32 (transposed operands)";
     VITA_REQUIRE(a.X && a.W && a.Y, "%s: X, W and Y must be non-null", who);
     VITA_REQUIRE(a.M > 0 && a.N > 0 && a.K >= 0, "%s: bad shape M=%d N=%d K=%d", who, a.M, a.N, a.K);
@@ -233,6 +238,7 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream) {
     p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
     p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
     p.epi.vec = epi_vec_ok(p.epi);
+    if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool vx = al(a.X) && a.ldx % 4 == 0 && (a.a_col ? a.M % 4 == 0 : a.K % 4 == 0);
     const bool vw = al(a.W) && a.ldw % 4 == 0 && (a.b_col ? a.N % 4 == 0 : a.K % 4 == 0);

@@ -25,11 +25,26 @@ struct Carver {
     }
 };
 
+// Split-K scratch of the running orchestrator (thread-local: entry points are re-entrant per stream/thread).  Every
+// vita_linear_args built by lin()/dgrad()/wgrad() inside the scope carries it.
+struct SplitkScratch { void* ptr = nullptr; size_t bytes = 0; };
+inline SplitkScratch& splitk_scratch() {
+    static thread_local SplitkScratch s;
+    return s;
+}
+struct SplitkScope {
+    SplitkScratch saved;
+    SplitkScope(void* p, size_t n) : saved(splitk_scratch()) { splitk_scratch().ptr = p; splitk_scratch().bytes = n; }
+    ~SplitkScope() { splitk_scratch() = saved; }
+};
+constexpr size_t kSplitkBytes = size_t(32) << 20;   // == vita_splitk_workspace_bytes()
+
 inline vita_linear_args lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* b, float* Y, int64_t ldy, int M,
                             int N, int K, int act) {
     vita_linear_args a{};
     a.X = X; a.ldx = ldx; a.W = W; a.ldw = ldw; a.bias = b; a.Y = Y; a.ldy = ldy;
     a.M = M; a.N = N; a.K = K; a.act = act;
+    a.splitk_ws = splitk_scratch().ptr; a.splitk_ws_bytes = splitk_scratch().bytes;
     return a;
 }
 // dX[M, in] = dY[M, out] . W[out, in]  (autograd of F.linear w.r.t. its input)

@@ -379,7 +379,7 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
 // whole-step workspace
 // ------------------------------------------------------------------------------------------------
 struct StepWs {
-    float *consts, *loss_part, *cs_part;
+    float *sk, *consts, *loss_part, *cs_part;
     float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
     float *ut, *vt, *dut, *dxt, *dxa, *dxb;
     FlowTrainWs flow;
@@ -403,6 +403,7 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     StepWs s{};
     const size_t D = w.flow.D;
     const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0;
+    s.sk = c.take(kSplitkBytes / sizeof(float));
     s.consts = c.take(16);
     s.loss_part = c.take((size_t)vita_loss_partials_count());
     s.cs_part = c.take((size_t)vita_colsum_partials_count(max_colsum_n(w)));
@@ -510,6 +511,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     float* pred = s.ZZ;
     float* z1 = s.ZZ + (size_t)B * D;
     FlowCtx fc{&w->flow, s.flow, B, K, 1 + K, st};
+    SplitkScope skscope(s.sk, kSplitkBytes);
 
     // loss weights as device scalars (seeds of the backward pass) ; zero the outputs
     const float seeds[4] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight};
@@ -626,6 +628,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
 size_t vita_action_encoder_workspace_bytes(const vita_encoder_weights* w, int32_t B) {
     if (!w || B <= 0) return 0;
     Carver c(nullptr);
+    c.take(kSplitkBytes / sizeof(float));
     if (w->kind == VITA_ENC_SIMPLE) carve_stack(c, stack_of_simple_encoder(*w), (size_t)B * w->T, false);
     else carve_cnn(c, *w, (size_t)B, false);
     return c.off;
@@ -642,6 +645,7 @@ int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* 
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_action_encoder_workspace_bytes(w, B), who));
     Carver c(workspace);
     StepWs s{};
+    SplitkScope skscope(c.take(kSplitkBytes / sizeof(float)), kSplitkBytes);
     if (w->kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(*w), (size_t)B * w->T, false);
     else s.cnn = carve_cnn(c, *w, (size_t)B, false);
     return encoder_fwd(*w, s, actions, latents, ldl, B, (hipStream_t)stream);

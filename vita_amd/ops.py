@@ -57,6 +57,20 @@ def workspace(device: torch.device, nbytes: int) -> Tensor:
     return buf
 
 
+_splitk: dict = {}
+
+
+def _splitk_ws(device: torch.device, a) -> Tensor:
+    """Per-(device, stream) split-K scratch for single vita_linear_f32 calls; returned so the caller keeps it alive."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _splitk.get(key)
+    if buf is None:
+        buf = torch.empty(L.load().vita_splitk_workspace_bytes(), dtype=torch.uint8, device=device)
+        _splitk[key] = buf
+    a.splitk_ws, a.splitk_ws_bytes = buf.data_ptr(), buf.numel()
+    return buf
+
+
 # --------------------------------------------------------------------------------------
 # fused linear
 # --------------------------------------------------------------------------------------
@@ -102,6 +116,7 @@ def linear(x: Tensor, w: Tensor, b: Optional[Tensor] = None, act: int = L.ACT_NO
     if resid is not None:
         resid = _rows(resid, "linear: resid")
         a.resid, a.ld_resid = resid.data_ptr(), _ld(resid)
+    _splitk_ws(x.device, a)
     L.check(lib.vita_linear_f32(C.byref(a), _stream(x)), "vita_linear_f32")
     return out
 
@@ -397,6 +412,7 @@ def linear_t(x: Tensor, w: Tensor, *, a_col: bool = False, b_col: bool = False, 
         a.use_gate_scalar, a.gate_scalar = 1, float(gate_scalar)
     if resid is not None:
         a.resid, a.ld_resid = resid.data_ptr(), _ld(resid)
+    _splitk_ws(x.device, a)
     L.check(lib.vita_linear_f32(C.byref(a), _stream(x)), "vita_linear_f32 (transposed)")
     return out
 
