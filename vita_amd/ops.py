@@ -680,7 +680,14 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
     dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
     ev = None
     if grad_ready_events is not None:
-        ev = (L.c_fp * 3)(*[e.cuda_event if e is not None else None for e in grad_ready_events])
+        handles = []
+        for e in grad_ready_events:
+            h = e.cuda_event if e is not None else None
+            if e is not None and not h:
+                raise L.VitaHipError("compute_loss: grad_ready event has no hipEvent_t yet (torch creates it on the first "
+                                     "record(): call event.record() once before passing it)")
+            handles.append(h)
+        ev = (L.c_fp * 3)(*handles)
     nbytes = lib.vita_compute_loss_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
     ws = workspace(dev, nbytes)
     L.check(lib.vita_compute_loss_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),

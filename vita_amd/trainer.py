@@ -41,7 +41,11 @@ class PolicyTrainer:
         self.rank, self.world = world_info(group)
         self.reducer = BucketReducer(self.flat_grad, policy.bucket_ranges, group, max_bucket_elems)
         self.overlap = overlap
-        self.events = [torch.cuda.Event() for _ in range(3)] if self.world > 1 else None
+        self.events = None
+        if self.world > 1:
+            self.events = [torch.cuda.Event() for _ in range(3)]
+            for e in self.events:   # torch creates the hipEvent_t lazily, on the first record: the C side needs the handle
+                e.record(torch.cuda.current_stream(self.device))
         self.num_training_steps = num_training_steps or config.train.steps
         self.step_counter = 0
         self.losses = torch.zeros(L.LOSS_COUNT, dtype=torch.float32, device=self.device)
