@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="rows per GPU")
     ap.add_argument("--ode-steps", type=int, default=6)
     ap.add_argument("--task", default="hook_package", choices=sorted(TASKS))
+    ap.add_argument("--hidden", type=int, default=512, help="flow-net hidden_dim (BASELINE configs[4]: 1024 / 2048 = the wide velocity net)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--train-batch", type=int, default=128, help="training rows per GPU (default_policy.yaml:34)")
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0 = same as --steps)")
@@ -68,7 +69,7 @@ def main():
 
     obs_dim, A = TASKS[args.task]
     B, K = args.batch, args.ode_steps
-    sd = O.make_state_dict(obs_dim, A, seed=0)
+    sd = O.make_state_dict(obs_dim, A, hidden_dim=args.hidden, seed=0)
     fw, dw = ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev)
     ow, ob = sd["obs_encoder.weight"].to(dev), sd["obs_encoder.bias"].to(dev)
     g = torch.Generator().manual_seed(1 + rank)
@@ -116,7 +117,9 @@ def main():
 
     # ---- training leg: data-parallel train_step (normalize -> fused fwd+bwd -> bucketed all-reduce -> clip+AdamW+EMA)
     train = None
-    if not args.no_train:
+    if not args.no_train and args.hidden != 512:
+        print("bench.py: the training leg uses the default policy dims; skipped for --hidden != 512", file=sys.stderr)
+    if not args.no_train and args.hidden == 512:
         from vita_amd.config import default_config
         from vita_amd.policy import VitaPolicy
         from vita_amd.trainer import PolicyTrainer
@@ -187,13 +190,13 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    FC1 = "fc1 gemm_f32_dma<128,128,32,4> 4096x2048x512 bias+gelu_tanh"
+    FC1 = f"fc1 gemm_f32_dma<128,128,32,4> {B}x{fw.FF}x{fw.H} bias+gelu_tanh"
     kernels = {}
     if rank == 0:
         for name, (M, N, Kd, kw) in {
             FC1: (B, fw.FF, fw.H, dict(act=_lib.ACT_GELU_TANH)),
-            "fc2 gemm_f32_dma<64,128,32,4> 4096x512x2048 bias+gate+resid": (B, fw.H, fw.FF, dict(gated=True)),
-            "in_proj gemm_f32_dma<64,128,32,4> 4096x512x512 bias": (B, fw.H, fw.D, dict()),
+            f"fc2 gemm_f32_dma<64,128,64,3> {B}x{fw.H}x{fw.FF} bias+gate+resid": (B, fw.H, fw.FF, dict(gated=True)),
+            f"in_proj gemm_f32_dma<64,128,64,3> {B}x{fw.H}x{fw.D} bias": (B, fw.H, fw.D, dict()),
         }.items():
             dt = time_linear(M, N, Kd, **kw)
             fl = 2.0 * M * N * Kd

@@ -299,6 +299,19 @@ def test_euler_linearity_property(ops, dev):
         close(traj[k + 1], step, 2e-6, f"step {k}")
 
 
+@pytest.mark.parametrize("H", [1024, 2048])
+def test_wide_velocity_net(ops, dev, H):
+    """BASELINE configs[4]: thread_needle dims with flow_net.hidden_dim 1024 / 2048 (the weights no longer fit L2)."""
+    sd = O.make_state_dict(533, 21, hidden_dim=H, seed=3)
+    fw, dw = ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev)
+    g = torch.Generator().manual_seed(H)
+    obs = torch.randn(256, 533, generator=g)
+    acts = ops.generate_actions(sd["obs_encoder.weight"].to(dev), sd["obs_encoder.bias"].to(dev), fw, dw, obs.to(dev), 6)
+    idx = torch.tensor([0, 1, 127, 128, 254, 255])
+    ref = O.generate_actions(O.cast_sd(sd, torch.float64), obs[idx].double(), 6, 16, 21).reshape(len(idx), -1)
+    close(acts[idx.to(dev)], ref, TOL, f"H={H}")
+
+
 def test_many_steps_k100(ops, dev):
     sd = O.make_state_dict(555, 7, seed=0)
     fw = ops.FlowNetHandle(sd, dev)

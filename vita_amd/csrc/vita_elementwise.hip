@@ -151,62 +151,89 @@ __global__ __launch_bounds__(EW_THREADS) void norm_kernel(const float* __restric
 // y = ((x - mean) * rstd) * m + a,  m = mul (+1 when MOD), two-pass statistics held in registers.
 // The row (H floats) is read once: lane l holds float4 chunks l, l+64, ... (H <= 64*4*LN_MAXC).
 constexpr int LN_MAXC = 8;
+// NC = float4 chunks per lane (H <= 256*NC), ROWS = rows per wave: all of a wave's loads are issued before the first
+// reduction so several rows are in flight per wave (at one row per wave the kernel ran at 2.1 TB/s, latency-bound).
+template <int NC, int ROWS>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                      int M, int H, float eps, int mod, const float* __restrict__ mul, int64_t ld_mul,
                                                      const float* __restrict__ add, int64_t ld_add, int vec) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= M) return;
-    const float* xr = x + (int64_t)row * ldx;
-    float* yr = y + (int64_t)row * ldy;
-    const float* mr = mul + (int64_t)row * ld_mul;
-    const float* ar = add + (int64_t)row * ld_add;
-    f32x4 v[LN_MAXC];
-    float s = 0.f;
+    const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
+    if (row0 >= M) return;
+    f32x4 v[ROWS][NC];
+    float s[ROWS];
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int k = (c * 64 + lane) * 4;
-        v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (k < H) {
-            if (vec) v[c] = *reinterpret_cast<const f32x4*>(xr + k);
-            else {
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = min(row0 + r, M - 1);
+        const float* xr = x + (int64_t)row * ldx;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (k + j < H) v[c][j] = xr[k + j];
-            }
-        }
-        s += (v[c][0] + v[c][1]) + (v[c][2] + v[c][3]);
-    }
-    s = wave_sum(s);
-    const float mu = s / (float)H;
-    float q = 0.f;
+        for (int c = 0; c < NC; ++c) {
+            const int k = (c * 64 + lane) * 4;
+            v[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (k < H) {
+                if (vec) v[r][c] = *reinterpret_cast<const f32x4*>(xr + k);
+                else {
 #pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int k = (c * 64 + lane) * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float d = (k + j < H) ? v[c][j] - mu : 0.f;
-            q = fmaf(d, d, q);
-        }
-    }
-    q = wave_sum(q);
-    const float rstd = 1.0f / sqrtf(q / (float)H + eps);
-#pragma unroll
-    for (int c = 0; c < LN_MAXC; ++c) {
-        const int k = (c * 64 + lane) * 4;
-        if (k < H) {
-            f32x4 o;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k + j < H) {
-                    const float n = (v[c][j] - mu) * rstd;
-                    const float m = mod ? (mr[k + j] + 1.0f) : mr[k + j];
-                    o[j] = n * m + ar[k + j];
+                    for (int j = 0; j < 4; ++j) if (k + j < H) v[r][c][j] = xr[k + j];
                 }
             }
-            if (vec) *reinterpret_cast<f32x4*>(yr + k) = o;
-            else {
+        }
+    }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) if (k + j < H) yr[k + j] = o[j];
+    for (int r = 0; r < ROWS; ++r) {
+        float t = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) t += (v[r][c][0] + v[r][c][1]) + (v[r][c][2] + v[r][c][3]);
+        s[r] = wave_sum(t);
+    }
+    float mu[ROWS], rstd[ROWS];
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        mu[r] = s[r] / (float)H;
+        float q = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = (c * 64 + lane) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = (k + j < H) ? v[r][c][j] - mu[r] : 0.f;
+                q = fmaf(d, d, q);
+            }
+        }
+        q = wave_sum(q);
+        rstd[r] = 1.0f / sqrtf(q / (float)H + eps);
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+        const int row = row0 + r;
+        if (row >= M) break;
+        float* yr = y + (int64_t)row * ldy;
+        const float* mr = mul + (int64_t)row * ld_mul;
+        const float* ar = add + (int64_t)row * ld_add;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int k = (c * 64 + lane) * 4;
+            if (k < H) {
+                f32x4 o;
+                if (vec) {
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(mr + k), a4 = *reinterpret_cast<const f32x4*>(ar + k);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float n = (v[r][c][j] - mu[r]) * rstd[r];
+                        const float m = mod ? (m4[j] + 1.0f) : m4[j];
+                        o[j] = n * m + a4[j];
+                    }
+                    *reinterpret_cast<f32x4*>(yr + k) = o;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (k + j < H) {
+                            const float n = (v[r][c][j] - mu[r]) * rstd[r];
+                            const float m = mod ? (mr[k + j] + 1.0f) : mr[k + j];
+                            yr[k + j] = n * m + ar[k + j];
+                        }
+                    }
+                }
             }
         }
     }
@@ -220,9 +247,17 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
                  "vita_layernorm_modulate_f32: bad leading dimension");
     VITA_REQUIRE(mode == VITA_PRO_LN_MOD || mode == VITA_PRO_LN_AFFINE, "vita_layernorm_modulate_f32: mode must be LN_MOD or LN_AFFINE");
     if (M == 0) return VITA_OK;
-    const int vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y);
-    hipLaunchKernelGGL(ln_mod_kernel, dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps, mode == VITA_PRO_LN_MOD ? 1 : 0,
-                       mul, ld_mul, add, ld_add, vec);
+    const int vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y) && al16(mul) && al16(add) &&
+                    (ld_mul % 4 == 0) && (ld_add % 4 == 0);
+    const int md = mode == VITA_PRO_LN_MOD ? 1 : 0;
+#define VITA_LN(NC, ROWS)                                                                                                       \
+    hipLaunchKernelGGL((ln_mod_kernel<NC, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps, md, \
+                       mul, ld_mul, add, ld_add, vec)
+    if (H <= 256) VITA_LN(1, 4);
+    else if (H <= 512) VITA_LN(2, 4);
+    else if (H <= 1024) VITA_LN(4, 2);
+    else VITA_LN(8, 1);
+#undef VITA_LN
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
