@@ -76,6 +76,8 @@ def main():
     obs = torch.randn(B, obs_dim, generator=g).to(dev)
     out = torch.empty(B, dw.OUT, device=dev)
 
+    fpc = flops_per_chunk(obs_dim, fw.D, fw.H, fw.FF, fw.L, K, dw.HD, dw.w.NL, dw.OUT)
+
     def step():
         ops.generate_actions(ow, ob, fw, dw, obs, K, out=out)
 
@@ -99,7 +101,6 @@ def main():
         elapsed = t.item()
     ms_per_step = elapsed * 1e3 / args.steps
     chunks_per_s = world * B * args.steps / elapsed
-    fpc = flops_per_chunk(obs_dim, fw.D, fw.H, fw.FF, fw.L, K, dw.HD, dw.w.NL, dw.OUT)
 
     # latent-only sampler (B,D)->(B,D): "the fused ODE sampler" of the north star
     x0 = torch.randn(B, fw.D, generator=g).to(dev)
@@ -114,6 +115,27 @@ def main():
     lat_ms = (time.perf_counter() - t0) * 1e3 / n_lat
     f_step = 2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D
     lat_tflops = B * K * f_step / (lat_ms * 1e-3) / 1e12
+
+    # ---- bf16-operand variant of the same path (side figure: NOT the headline, the reference is strict fp32)
+    bf16 = None
+    if rank == 0:
+        bw = ops.Bf16Weights(sd, dev)
+        outb = torch.empty_like(out)
+        for _ in range(3):
+            ops.generate_actions_bf16(ob, fw, dw, bw, obs, K, out=outb)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        nb = max(5, args.steps)
+        for _ in range(nb):
+            ops.generate_actions_bf16(ob, fw, dw, bw, obs, K, out=outb)
+        torch.cuda.synchronize(dev)
+        bms = (time.perf_counter() - t0) * 1e3 / nb
+        step()
+        torch.cuda.synchronize(dev)
+        err = ((outb - out).abs().max() / out.abs().max()).item()
+        bf16 = {"value": round(B / (bms * 1e-3), 1), "unit": "action-chunks/s", "ms_per_step": round(bms, 4), "dtype": "bf16 operands, f32 accumulate",
+                "tflops": round(B * fpc / (bms * 1e-3) / 1e12, 2), "frac_of_bf16_mfma_peak": round(B * fpc / (bms * 1e-3) / 1e12 / 2500.0, 4),
+                "normalised_max_error_vs_f32_path": float(f"{err:.3g}"), "stated_tolerance": 2e-2}
 
     # ---- training leg: data-parallel train_step (normalize -> fused fwd+bwd -> bucketed all-reduce -> clip+AdamW+EMA)
     train = None
@@ -257,6 +279,7 @@ def main():
                          "flops_per_launch": 2.0 * B * fw.FF * fw.H},
             "kernels": kernels,
             "train": train,
+            "bf16_variant": bf16,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -331,6 +331,37 @@ size_t vita_action_encoder_workspace_bytes(const vita_encoder_weights* w, int32_
 int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* actions, float* latents, int64_t ldl, int32_t B,
                                     void* workspace, size_t workspace_bytes, vita_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * bf16-operand inference (north star (b); BASELINE configs[2]).  GEMM operands are bf16, everything else (accumulators,
+ * bias, activations, LayerNorm, residual / Euler state, time path) fp32.  NOT bit-comparable with the fp32 reference:
+ * the stated tolerance is 2e-2 normalised max error on the actions (tests/test_gpu_bf16.py).
+ * --------------------------------------------------------------------------------------- */
+/* fp32 (rows, cols) -> bf16 (rows, ld_dst), zero-filling columns cols..ld_dst-1.  bf16 GEMM operands need row strides
+ * and K that are multiples of 8: pack with ld_dst = (cols + 7) & ~7. */
+int vita_pack_bf16_f32(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int32_t cols, vita_stream_t stream);
+
+/* vita_linear_f32 with bf16 X and W (args->X / args->W point at bf16 data; K, ldx, ldw count bf16 elements, multiples of
+ * 8, 16-byte aligned rows).  Y (fp32) and / or y_bf16 receive the result; the epilogue options are those of
+ * vita_linear_f32 except the LayerNorm prologue and transposed operands. */
+int vita_linear_bf16(const vita_linear_args* args, uint16_t* y_bf16, int64_t ld_ybf, vita_stream_t stream);
+
+typedef struct vita_bf16_weights { /* vita_pack_bf16_f32 copies of the GEMM weights, row stride = (K + 7) & ~7 */
+    const uint16_t* obs_w;                                            /* obs_encoder.weight */
+    const uint16_t *in_w, *out_w;                                     /* flow_net.input_proj / out_proj */
+    const uint16_t *fc1_w[VITA_MAX_LAYERS], *fc2_w[VITA_MAX_LAYERS];  /* flow_net.layers.l.mlp.fc1 / fc2 */
+    const uint16_t *dec_in_w, *dec_out_w;                             /* action_decoder.input_proj / output_proj */
+    const uint16_t *dec_fc1_w[VITA_MAX_LAYERS], *dec_fc2_w[VITA_MAX_LAYERS];
+} vita_bf16_weights;
+
+/* VitaPolicy.generate_actions (vita_policy.py:191-208) with bf16 GEMM operands; biases, LayerNorm and time-path weights
+ * come from the fp32 descriptors. */
+size_t vita_generate_actions_bf16_workspace_bytes(const vita_flownet_weights* fw, const vita_decoder_weights* dw, int32_t O, int32_t B,
+                                                  int32_t num_steps);
+int vita_generate_actions_bf16(const float* obs_b, int32_t O, const vita_flownet_weights* fw, const vita_decoder_weights* dw,
+                               const vita_bf16_weights* bw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                               float* latents_out, int32_t B, int32_t num_steps, void* workspace, size_t workspace_bytes,
+                               vita_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -90,6 +90,15 @@ class LossConfig(C.Structure):
     ]
 
 
+class Bf16Weights(C.Structure):
+    _fields_ = [
+        ("obs_w", c_fp), ("in_w", c_fp), ("out_w", c_fp),
+        ("fc1_w", _PA), ("fc2_w", _PA),
+        ("dec_in_w", c_fp), ("dec_out_w", c_fp),
+        ("dec_fc1_w", _PA), ("dec_fc2_w", _PA),
+    ]
+
+
 ENC_CNN, ENC_SIMPLE = 0, 1
 LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss")
 LOSS_COUNT = 8
@@ -141,6 +150,13 @@ SIGNATURES = {
     "vita_sumsq_f32": (C.c_int, [c_fp, C.c_int64, c_fp, c_fp, c_fp]),
     "vita_adamw_ema_step_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, c_fp, C.c_float, C.c_float, C.c_double,
                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, c_fp]),
+    "vita_pack_bf16_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int64, C.c_int32, c_fp]),
+    "vita_linear_bf16": (C.c_int, [C.POINTER(LinearArgs), c_fp, C.c_int64, c_fp]),
+    "vita_generate_actions_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights), C.c_int32,
+                                                                C.c_int32, C.c_int32]),
+    "vita_generate_actions_bf16": (C.c_int, [c_fp, C.c_int32, C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
+                                             C.POINTER(Bf16Weights), c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int32, C.c_int32,
+                                             c_fp, C.c_size_t, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

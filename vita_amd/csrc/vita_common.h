@@ -9,6 +9,8 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
 
 namespace vita {
 
@@ -105,6 +107,13 @@ __device__ __forceinline__ float act_grad(float z, int act) {
         default: return 1.f;
     }
 }
+
+// fp32 -> bf16, round to nearest even (hipcc emits v_cvt_pk_bf16_f32 on gfx950; NaN stays NaN)
+__device__ __forceinline__ uint16_t f32_to_bf16(float x) {
+    const __bf16 b = (__bf16)x;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf16_to_f32(uint16_t v) { return __builtin_bit_cast(float, (uint32_t)v << 16); }
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -156,7 +156,8 @@ constexpr int LN_MAXC = 8;
 template <int NC, int ROWS>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                      int M, int H, float eps, int mod, const float* __restrict__ mul, int64_t ld_mul,
-                                                     const float* __restrict__ add, int64_t ld_add, int vec) {
+                                                     const float* __restrict__ add, int64_t ld_add, int vec, uint16_t* __restrict__ ybf,
+                                                     int64_t ld_ybf) {
     const int lane = threadIdx.x & 63;
     const int row0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * ROWS;
     if (row0 >= M) return;
@@ -223,14 +224,22 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
                         const float m = mod ? (m4[j] + 1.0f) : m4[j];
                         o[j] = n * m + a4[j];
                     }
-                    *reinterpret_cast<f32x4*>(yr + k) = o;
+                    if (y) *reinterpret_cast<f32x4*>(yr + k) = o;
+                    if (ybf) {   // bf16 copy: the next bf16 GEMM's A operand
+                        u16x4 hb;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) hb[j] = f32_to_bf16(o[j]);
+                        *reinterpret_cast<u16x4*>(ybf + (int64_t)row * ld_ybf + k) = hb;
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         if (k + j < H) {
                             const float n = (v[r][c][j] - mu[r]) * rstd[r];
                             const float m = mod ? (mr[k + j] + 1.0f) : mr[k + j];
-                            yr[k + j] = n * m + ar[k + j];
+                            const float o1 = n * m + ar[k + j];
+                            if (y) yr[k + j] = o1;
+                            if (ybf) ybf[(int64_t)row * ld_ybf + k + j] = f32_to_bf16(o1);
                         }
                     }
                 }
@@ -240,19 +249,21 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
 }
 
 int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
-                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s) {
-    VITA_REQUIRE(x && y && mul && add, "vita_layernorm_modulate_f32: null pointer");
+                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s, uint16_t* ybf, int64_t ld_ybf) {
+    VITA_REQUIRE(x && (y || ybf) && mul && add, "vita_layernorm_modulate_f32: null pointer");
+    VITA_REQUIRE(ybf == nullptr || (ld_ybf >= H && ld_ybf % 4 == 0 && (reinterpret_cast<uintptr_t>(ybf) & 7u) == 0),
+                 "vita_layernorm_modulate: bf16 output needs ld >= H, ld %% 4 == 0 and 8-byte alignment");
     VITA_REQUIRE(M >= 0 && H > 0 && H <= 64 * 4 * LN_MAXC, "vita_layernorm_modulate_f32: H=%d outside (0, %d]", H, 64 * 4 * LN_MAXC);
-    VITA_REQUIRE(ldx >= H && ldy >= H && (ld_mul == 0 || ld_mul >= H) && (ld_add == 0 || ld_add >= H),
+    VITA_REQUIRE(ldx >= H && (y == nullptr || ldy >= H) && (ld_mul == 0 || ld_mul >= H) && (ld_add == 0 || ld_add >= H),
                  "vita_layernorm_modulate_f32: bad leading dimension");
     VITA_REQUIRE(mode == VITA_PRO_LN_MOD || mode == VITA_PRO_LN_AFFINE, "vita_layernorm_modulate_f32: mode must be LN_MOD or LN_AFFINE");
     if (M == 0) return VITA_OK;
-    const int vec = (H % 4 == 0) && (ldx % 4 == 0) && (ldy % 4 == 0) && al16(x) && al16(y) && al16(mul) && al16(add) &&
+    const int vec = (H % 4 == 0) && (ldx % 4 == 0) && (y == nullptr || (ldy % 4 == 0 && al16(y))) && al16(x) && al16(mul) && al16(add) &&
                     (ld_mul % 4 == 0) && (ld_add % 4 == 0);
     const int md = mode == VITA_PRO_LN_MOD ? 1 : 0;
 #define VITA_LN(NC, ROWS)                                                                                                       \
     hipLaunchKernelGGL((ln_mod_kernel<NC, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps, md, \
-                       mul, ld_mul, add, ld_add, vec)
+                       mul, ld_mul, add, ld_add, vec, ybf, ld_ybf)
     if (H <= 256) VITA_LN(1, 4);
     else if (H <= 512) VITA_LN(2, 4);
     else if (H <= 1024) VITA_LN(4, 2);
@@ -282,6 +293,17 @@ __global__ __launch_bounds__(EW_THREADS) void sinusoid_kernel(const float* __res
 __global__ void step_times_kernel(float* __restrict__ ts, int K) {
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k < K) ts[k] = (float)((double)k / (double)K);
+}
+
+// fp32 (rows, cols) -> bf16 (rows, ld_dst), columns cols..ld_dst-1 zero-filled (so a GEMM may reduce over ld_dst)
+__global__ __launch_bounds__(EW_THREADS) void pack_bf16_kernel(const float* __restrict__ src, int64_t ld_src, uint16_t* __restrict__ dst,
+                                                             int64_t ld_dst, int64_t rows, int cols) {
+    const int64_t n = rows * ld_dst, stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / ld_dst;
+        const int c = (int)(i - r * ld_dst);
+        dst[i] = c < cols ? f32_to_bf16(src[r * ld_src + c]) : (uint16_t)0;
+    }
 }
 
 int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s) {
@@ -355,7 +377,16 @@ int vita_unnormalize_f32(const float* x, const float* mean, const float* sd, flo
 
 int vita_layernorm_modulate_f32(const float* x, int64_t ldx, float* y, int64_t ldy, int32_t M, int32_t H, float eps, int32_t mode,
                                 const float* mul, int64_t ld_mul, const float* add, int64_t ld_add, vita_stream_t stream) {
-    return launch_ln_mod(x, ldx, y, ldy, M, H, eps, mode, mul, ld_mul, add, ld_add, (hipStream_t)stream);
+    return launch_ln_mod(x, ldx, y, ldy, M, H, eps, mode, mul, ld_mul, add, ld_add, (hipStream_t)stream, nullptr, 0);
+}
+
+int vita_pack_bf16_f32(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int32_t cols, vita_stream_t stream) {
+    VITA_REQUIRE(src && dst && rows >= 0 && cols > 0 && ld_src >= cols && ld_dst >= cols, "vita_pack_bf16_f32: bad arguments");
+    if (rows == 0) return VITA_OK;
+    hipLaunchKernelGGL(pack_bf16_kernel, dim3(ew_grid(rows * ld_dst, 4096)), dim3(EW_THREADS), 0, (hipStream_t)stream, src, ld_src, dst,
+                       ld_dst, rows, cols);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
 }
 
 int vita_sinusoidal_embed_f32(const float* t, float* out, int64_t ldo, int32_t B, int32_t dim, vita_stream_t stream) {

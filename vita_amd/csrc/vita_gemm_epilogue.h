@@ -30,6 +30,8 @@ struct EpiParams {
     // split-K: when `partial` is set the tile's raw accumulators go to partial[(split*M + row)*ld_partial + col] and
     // splitk_reduce_kernel applies the epilogue after summing the splits in a fixed order
     float* partial; int64_t ld_partial;
+    // optional bf16 copy of Y (the next bf16 GEMM's A operand); Y itself may then be NULL
+    uint16_t* ybf; int64_t ld_ybf;
 };
 
 // k-range of a split-K launch: blockIdx.x = split * tiles + tile; the split covers k in [split*k_per_split, ...)
@@ -44,7 +46,7 @@ inline bool epi_aligned(const void* q) { return (reinterpret_cast<uintptr_t>(q) 
 inline int epi_vec_ok(const EpiParams& e) {
     auto ok = [](const void* q, int64_t ld) { return q == nullptr || (epi_aligned(q) && ld % 4 == 0); };
     return ok(e.Y, e.ldy) && ok(e.bias, 0) && ok(e.gate, e.ld_gate) && ok(e.resid, e.ld_resid) && ok(e.preact, e.ld_preact) &&
-           ok(e.act_grad_z, e.ld_act_grad_z);
+           ok(e.act_grad_z, e.ld_act_grad_z) && ok(e.ybf, e.ld_ybf);
 }
 
 template <int ACT, bool BWD>
@@ -116,7 +118,13 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                 pre[k] = p_;
             }
             if (e.preact) *reinterpret_cast<f32x4*>(e.preact + (int64_t)row * e.ld_preact + col) = pre;
-            *reinterpret_cast<f32x4*>(e.Y + (int64_t)row * e.ldy + col) = out;
+            if (e.Y) *reinterpret_cast<f32x4*>(e.Y + (int64_t)row * e.ldy + col) = out;
+            if (e.ybf) {
+                u16x4 hb;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(out[k]);
+                *reinterpret_cast<u16x4*>(e.ybf + (int64_t)row * e.ld_ybf + col) = hb;
+            }
         } else {
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -130,7 +138,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                 float p_ = 0.f;
                 const float v = epi_elem<ACT, BWD>(a[k], b, zin, g, has_gate, rs, has_resid, e.preact ? &p_ : nullptr);
                 if (e.preact) e.preact[(int64_t)row * e.ld_preact + cc] = p_;
-                e.Y[(int64_t)row * e.ldy + cc] = v;
+                if (e.Y) e.Y[(int64_t)row * e.ldy + cc] = v;
+                if (e.ybf) e.ybf[(int64_t)row * e.ld_ybf + cc] = f32_to_bf16(v);
             }
         }
     }

@@ -94,7 +94,10 @@ __device__ __forceinline__ int swz(int r) {
 }
 
 // OCC = waves per SIMD the register allocation must allow (2 = one 512-thread workgroup per CU, 4 = two)
-template <int BM, int BN, int BK, int NS, bool LN, int OCC>
+// BF16: the operand bytes are bf16 (p.K / p.ldx / p.ldw count 4-byte units = bf16 pairs, BK 4-byte units = 2*BK bf16 of
+// reduction): same DMA / LDS image, and the 16-byte fragment a lane reads IS the 8-deep bf16 operand of one
+// v_mfma_f32_32x32x16_bf16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15), so one MFMA replaces the four fp32 ones.
+template <int BM, int BN, int BK, int NS, bool LN, int OCC, bool BF16 = false>
 __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p) {
     constexpr int CH = BK / 4;                 // 16-byte chunks per tile row
     constexpr int RPI = 64 / CH;               // rows covered by one DMA wave-instruction
@@ -328,13 +331,22 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
             if (kc + 1 < NCH) read_frags(stage, kt, kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1], lm[(kc + 1) & 1], la[(kc + 1) & 1]);
             else read_frags(stage1, kt + 1, 0, af[0], bf[0], lm[0], la[0]);
             ln_apply(af[kc & 1], lm[kc & 1], la[kc & 1]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+            if constexpr (BF16) {
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < NI; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][i][e], bf[kc & 1][j][e], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[kc & 1][i]),
+                                                                            __builtin_bit_cast(bf16x8, bf[kc & 1][j]), acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+#pragma unroll
+                        for (int j = 0; j < NI; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][i][e], bf[kc & 1][j][e], acc[i][j], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         // the prefetched fragments must be in registers before the next barrier lets anyone
@@ -352,6 +364,17 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     epilogue_dispatch<BM, BN, MI, NI, DNT, false>(acc, smem, e, m0, n0, wm, wn, lane, tid);
     STAMP(3);
     RSTAMP(5);
+}
+
+template <int BM, int BN, int BK, int NS>
+static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
+    GemmParamsDma p = p0;
+    p.tiles_m = (p.M + BM - 1) / BM;
+    p.tiles_n = (p.N + BN - 1) / BN;
+    const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(DNT), lds, stream, p);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
 }
 
 template <int BM, int BN, int BK, int NS, int OCC = 2>
@@ -406,6 +429,24 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 64, 3>(p, stream);
 #endif
+}
+
+// bf16 operands: a.X / a.W point at bf16 data, a.K / a.ldx / a.ldw count bf16 elements (multiples of 8, 16-byte aligned
+// rows); everything on the output side is as in the fp32 call, plus the optional bf16 copy of Y.
+int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream) {
+    GemmParamsDma p{};
+    p.X = a.X; p.ldx = a.ldx / 2; p.W = a.W; p.ldw = a.ldw / 2; p.bias = a.bias;
+    p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K / 2;
+    p.act = a.act; p.pro = VITA_PRO_NONE;
+    p.epi.Y = a.Y; p.epi.ldy = a.ldy; p.epi.M = a.M; p.epi.N = a.N; p.epi.bias = a.bias; p.epi.act = a.act;
+    p.epi.gate = a.gate; p.epi.ld_gate = a.ld_gate; p.epi.use_gate_scalar = a.use_gate_scalar;
+    p.epi.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
+    p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
+    p.epi.ybf = ybf; p.epi.ld_ybf = ld_ybf;
+    p.epi.vec = epi_vec_ok(p.epi);
+    const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (t128 >= 512) return launch_dma_bf16<128, 128, 32, 4>(p, stream);
+    return launch_dma_bf16<64, 128, 32, 4>(p, stream);
 }
 
 bool gemm_f32_dma_eligible(const vita_linear_args& a) {

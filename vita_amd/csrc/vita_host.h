@@ -9,7 +9,8 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream);
 int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
 int launch_step_times(float* ts, int K, hipStream_t s);
 int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
-                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s);
+                  int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s, uint16_t* ybf = nullptr, int64_t ld_ybf = 0);
+int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream);
 int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st);
 int launch_weighted_sum(const float* vals, const float* host_w, int n, float* out, hipStream_t st);
 

@@ -710,3 +710,91 @@ def action_encoder_forward(pw: PolicyHandle, actions: Tensor) -> Tensor:
     L.check(lib.vita_action_encoder_forward_f32(C.byref(pw.w.enc), actions.data_ptr(), z.data_ptr(), pw.D, B, ws.data_ptr(),
                                                 ws.numel(), _stream(actions)), "vita_action_encoder_forward_f32")
     return z
+
+
+# --------------------------------------------------------------------------------------
+# bf16-operand inference (fp32 accumulate / epilogue / residual stream)
+# --------------------------------------------------------------------------------------
+def pack_bf16(x: Tensor) -> Tensor:
+    """fp32 (rows, cols) -> bf16 bits (rows, round_up(cols, 8)) as an int16 tensor, zero-padded (vita_pack_bf16_f32)."""
+    lib = L.load()
+    x = _rows(x, "pack_bf16: x")
+    rows, cols = x.shape
+    ld = (cols + 7) & ~7
+    out = torch.empty((rows, ld), dtype=torch.int16, device=x.device)
+    L.check(lib.vita_pack_bf16_f32(x.data_ptr(), _ld(x), out.data_ptr(), ld, rows, cols, _stream(x)), "vita_pack_bf16_f32")
+    return out
+
+
+def linear_bf16(xb: Tensor, wb: Tensor, b: Optional[Tensor] = None, act: int = L.ACT_NONE, *, n_out: Optional[int] = None,
+                gate: Optional[Tensor] = None, gate_scalar: Optional[float] = None, resid: Optional[Tensor] = None,
+                out_f32: bool = True, out_bf16: bool = False):
+    """vita_linear_bf16 on packed operands (pack_bf16).  Returns (Y fp32 or None, Y bf16 bits or None)."""
+    lib = L.load()
+    M, Kp = xb.shape
+    N = n_out if n_out is not None else wb.shape[0]
+    if wb.shape[1] != Kp or xb.dtype != torch.int16 or wb.dtype != torch.int16:
+        raise L.VitaHipError("linear_bf16: operands must be pack_bf16 outputs with the same padded K")
+    y = torch.empty((M, N), dtype=torch.float32, device=xb.device) if out_f32 else None
+    ldb = (N + 7) & ~7
+    yb = torch.zeros((M, ldb), dtype=torch.int16, device=xb.device) if out_bf16 else None
+    a = L.LinearArgs()
+    a.X, a.ldx, a.W, a.ldw = xb.data_ptr(), Kp, wb.data_ptr(), Kp
+    a.bias = b.contiguous().data_ptr() if b is not None else None
+    a.Y, a.ldy = (y.data_ptr() if y is not None else None), N
+    a.M, a.N, a.K, a.act = M, N, Kp, act
+    keep = []
+    if gate is not None:
+        gate = gate.contiguous()
+        keep.append(gate)
+        a.gate, a.ld_gate = gate.data_ptr(), (0 if gate.dim() == 1 else N)
+    if gate_scalar is not None:
+        a.use_gate_scalar, a.gate_scalar = 1, float(gate_scalar)
+    if resid is not None:
+        resid = _rows(resid, "linear_bf16: resid")
+        a.resid, a.ld_resid = resid.data_ptr(), _ld(resid)
+    L.check(lib.vita_linear_bf16(C.byref(a), yb.data_ptr() if yb is not None else None, ldb, _stream(xb)), "vita_linear_bf16")
+    return y, yb
+
+
+class Bf16Weights:
+    """bf16 copies of the GEMM weights of a policy state dict (re-pack after every optimizer step that changes them)."""
+
+    def __init__(self, sd: Mapping[str, Tensor], device):
+        device = torch.device(device)
+        self.t = {}
+        g = lambda k: self.t.setdefault(k, pack_bf16(_prep(sd, k, device)))  # noqa: E731
+        w = L.Bf16Weights()
+        w.obs_w = g("obs_encoder.weight").data_ptr()
+        w.in_w, w.out_w = g("flow_net.input_proj.weight").data_ptr(), g("flow_net.out_proj.weight").data_ptr()
+        n = 0
+        while f"flow_net.layers.{n}.mlp.fc1.weight" in sd:
+            w.fc1_w[n] = g(f"flow_net.layers.{n}.mlp.fc1.weight").data_ptr()
+            w.fc2_w[n] = g(f"flow_net.layers.{n}.mlp.fc2.weight").data_ptr()
+            n += 1
+        w.dec_in_w, w.dec_out_w = g("action_decoder.input_proj.weight").data_ptr(), g("action_decoder.output_proj.weight").data_ptr()
+        n = 0
+        while f"action_decoder.layers.{n}.fc1.weight" in sd:
+            w.dec_fc1_w[n] = g(f"action_decoder.layers.{n}.fc1.weight").data_ptr()
+            w.dec_fc2_w[n] = g(f"action_decoder.layers.{n}.fc2.weight").data_ptr()
+            n += 1
+        self.w = w
+
+
+def generate_actions_bf16(obs_b: Tensor, fw: FlowNetHandle, dw: DecoderHandle, bw: Bf16Weights, obs_features: Tensor, num_steps: int,
+                          return_latents: bool = False, out: Optional[Tensor] = None):
+    """VitaPolicy.generate_actions with bf16 GEMM operands (vita_generate_actions_bf16)."""
+    lib = L.load()
+    obs_features = _rows(obs_features, "generate_actions_bf16: obs_features")
+    obs_b = _f32(obs_b, "generate_actions_bf16: obs_b").contiguous()
+    B, O = obs_features.shape
+    if out is None:
+        out = torch.empty((B, dw.OUT), dtype=torch.float32, device=obs_features.device)
+    lat = torch.empty((B, fw.D), dtype=torch.float32, device=obs_features.device) if return_latents else None
+    nbytes = lib.vita_generate_actions_bf16_workspace_bytes(C.byref(fw.w), C.byref(dw.w), O, B, num_steps)
+    ws = workspace(obs_features.device, nbytes)
+    L.check(lib.vita_generate_actions_bf16(obs_b.data_ptr(), O, C.byref(fw.w), C.byref(dw.w), C.byref(bw.w), obs_features.data_ptr(),
+                                           _ld(obs_features), out.data_ptr(), dw.OUT, lat.data_ptr() if lat is not None else None,
+                                           B, num_steps, ws.data_ptr(), ws.numel(), _stream(obs_features)),
+            "vita_generate_actions_bf16")
+    return (out, lat) if return_latents else out
