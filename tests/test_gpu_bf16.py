@@ -100,3 +100,28 @@ def test_generate_actions_bf16_b4096_rows_independent(ops):
     idx = torch.arange(0, 4096, 512)
     ref = O.generate_actions(sd, obs[idx].cpu(), 6, 16, 21).reshape(len(idx), -1)
     assert nerr(acts[idx.to(DEV)], ref) <= BF16_ACTION_TOL
+
+
+def test_policy_gemm_dtype_bf16_repacks_after_a_weight_update(ops):
+    from vita_amd.config import default_config
+    from vita_amd.policy import VitaPolicy
+    cfg = default_config("pusht")
+    cfg.policy.gemm_dtype = "bf16"
+    stats = {"observation.state": {"mean": [0.0, 0.0], "std": [1.0, 1.0]}, "action": {"mean": [0.0, 0.0], "std": [1.0, 1.0]}}
+    torch.manual_seed(0)
+    pol = VitaPolicy(cfg, stats).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    batch = {"observation.state": torch.randn(9, 1, 2, generator=g).to(DEV), "observation.features": torch.randn(9, 1, 512, generator=g).to(DEV)}
+    a1 = pol.generate_actions(batch)
+    sd = {k: p.detach().cpu() for k, p in pol.hot_path_named_parameters()}
+    feats = torch.cat([batch["observation.state"].flatten(1), batch["observation.features"].flatten(1)], 1).cpu()
+    ref = O.generate_actions(sd, feats, 6, 16, 2)
+    assert 1e-6 < nerr(a1, ref) <= BF16_ACTION_TOL
+    with torch.no_grad():
+        pol.action_decoder.output_proj.weight.mul_(2.0)      # an "optimizer step": the cached bf16 copy is now stale
+    a2 = pol.generate_actions(batch)
+    sd["action_decoder.output_proj.weight"] = sd["action_decoder.output_proj.weight"] * 2.0
+    assert nerr(a2, O.generate_actions(sd, feats, 6, 16, 2)) <= BF16_ACTION_TOL
+    cfg.policy.gemm_dtype = "fp8"
+    with pytest.raises(ValueError):
+        VitaPolicy(cfg, stats)

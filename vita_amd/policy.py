@@ -253,6 +253,11 @@ class VitaPolicy(nn.Module):
                                          consistency_weight=float(pol.vita.consistency_weight),
                                          enc_recon_weight=float(self.enc_action_recon_weight),
                                          flow_recon_weight=float(self.flow_action_recon_weight))
+        # GEMM operand type for INFERENCE: "f32" (default: the reference's strict-fp32 numerics) or "bf16" (bf16 MFMA operands,
+        # fp32 accumulate; stated tolerance 2e-2 on the actions).  Not a reference key: policy.gemm_dtype.
+        self.gemm_dtype = str(pol.get("gemm_dtype", "f32"))
+        if self.gemm_dtype not in ("f32", "bf16"):
+            raise ValueError(f"policy.gemm_dtype must be 'f32' or 'bf16', got {self.gemm_dtype!r}")
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -412,9 +417,23 @@ class VitaPolicy(nn.Module):
         """vita_policy.py:191-208: observer features -> obs_encoder -> K Euler steps -> decoder, one C-ABI call."""
         obs_features = self.observer(batch)
         fw, dw, _ = self._infer_handles()
-        out = ops.generate_actions(self.obs_encoder.weight.data, self.obs_encoder.bias.data, fw, dw, obs_features,
-                                   self.num_sampling_steps)
+        if self.gemm_dtype == "bf16":
+            out = ops.generate_actions_bf16(self.obs_encoder.bias.data, fw, dw, self._bf16_weights(), obs_features,
+                                            self.num_sampling_steps)
+        else:
+            out = ops.generate_actions(self.obs_encoder.weight.data, self.obs_encoder.bias.data, fw, dw, obs_features,
+                                       self.num_sampling_steps)
         return out.view(-1, self.pred_horizon, self.action_dim)
+
+    def _bf16_weights(self):
+        """bf16 copies of the GEMM weights, re-packed whenever a parameter has been written since the last pack."""
+        named = self.hot_path_named_parameters()
+        version = (self._key(), tuple(p._version for _, p in named))
+        c = self._cache.get("bf16")
+        if c is None or c[0] != version:
+            c = (version, ops.Bf16Weights({k: p.data for k, p in named}, self.obs_encoder.weight.device))
+            self._cache["bf16"] = c
+        return c[1]
 
     @torch.no_grad()
     def select_action(self, batch):
