@@ -61,10 +61,13 @@ def _worker(rank, world, port, out):
 @pytest.mark.timeout(120)
 def test_bucketed_allreduce_world2_gloo():
     world = 2
-    mgr = mp.Manager()
+    ctx = mp.get_context("spawn")   # never fork(): the parent may hold a HIP context when the whole suite runs in one process
+    mgr = ctx.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
-    assert dict(out) == {0: True, 1: True}
+    mp.start_processes(_worker, args=(world, _free_port(), out), nprocs=world, join=True, start_method="spawn")
+    res = dict(out)
+    mgr.shutdown()
+    assert res == {0: True, 1: True}
 
 
 def test_reducer_single_process_is_a_noop():

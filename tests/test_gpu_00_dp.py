@@ -1,7 +1,13 @@
 """GPU: the data-parallel train_step with two ranks (both on cuda:0, gloo backend — RCCL refuses two ranks on one
 device, and the box has one GPU; the trainer's event / side-stream / bucket logic is the same code for any backend).
+With gloo the reducer stages each bucket through pinned host memory itself (ProcessGroupGloo's own CUDA-tensor path hung
+intermittently here with two ranks on one device: 6 of 13 runs, always inside dist.all_reduce of the second step).
 Two ranks each train on half of a global batch; the result must equal one process training on the whole batch:
-equal shard sizes => mean of the shard-mean gradients == global-batch-mean gradient."""
+equal shard sizes => mean of the shard-mean gradients == global-batch-mean gradient.
+
+Process hygiene: the file name sorts first among the GPU tests so that the parent has not initialised HIP when the ranks
+are started, and every helper process (ranks AND the result manager) is created with the "spawn" method: a fork()ed copy
+of a process that holds a HIP context hung intermittently on the GPU box."""
 import os
 import socket
 
@@ -55,6 +61,10 @@ STEPS, B = 3, 32
 
 
 def _worker(rank, world, port, out):
+    import faulthandler
+    dbg = os.environ.get("VITA_DP_DEBUG_DIR")
+    if dbg:   # where a rank is stuck, should it ever hang: stacks of all threads after 40 s
+        faulthandler.dump_traceback_later(40, repeat=False, file=open(os.path.join(dbg, f"dp_rank{rank}.txt"), "w"), exit=True)
     import torch.distributed as dist
     from vita_amd.parallel import shard_range
     from vita_amd.trainer import PolicyTrainer
@@ -84,12 +94,14 @@ def _worker(rank, world, port, out):
 def test_two_rank_data_parallel_equals_single_process_on_the_global_batch():
     from vita_amd.trainer import PolicyTrainer
     world = 2
-    mgr = mp.Manager()
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
     out = mgr.dict()
-    mp.spawn(_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    mp.start_processes(_worker, args=(world, _free_port(), out), nprocs=world, join=True, start_method="spawn")
     assert set(out.keys()) == {0, 1}
     p0, e0, gn0 = out[0]
     p1, e1, gn1 = out[1]
+    mgr.shutdown()
     d = (p0 - p1).abs()
     assert torch.equal(p0, p1) and torch.equal(e0, e1), f"replicas diverged: max {d.max().item():g} at {d.argmax().item()} of {d.numel()}, {int((d > 0).sum())} differ"
     cfg = _cfg()

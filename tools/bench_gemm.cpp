@@ -49,6 +49,7 @@ int main(int argc, char** argv) {
     {
         int tiles = ((M + 127) / 128) * ((N + 127) / 128);
         if (tiles < 512) tiles = ((M + 63) / 64) * ((N + 127) / 128);
+        if (getenv("TILES")) tiles = atoi(getenv("TILES"));
         if (tiles > 4096) tiles = 4096;
         std::vector<unsigned long long> st(tiles * 8);
         CK(hipDeviceSynchronize());

@@ -412,7 +412,7 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
     if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
 #ifndef VITA_DMA_CFG
-#define VITA_DMA_CFG 4
+#define VITA_DMA_CFG 5
 #endif
 #if VITA_DMA_CFG == 0
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
@@ -425,7 +425,11 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
 #elif VITA_DMA_CFG == 3
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 32, 3>(p, stream);
-#else   // 4: deeper k-tiles for the 64-row tile (one barrier per 32 MFMAs per wave): fc2 95.4 -> 89.6 us
+#elif VITA_DMA_CFG == 4   // deeper k-tiles for the 64-row tile (one barrier per 32 MFMAs per wave): fc2 95.4 -> 89.6 us
+    if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
+    return launch_dma<64, 128, 64, 3>(p, stream);
+#else   // 5: 256x128 tiles when they still give every CU a tile (6 DMA issues per 64 MFMAs per wave instead of 4 per 32)
+    if ((long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= 256 && sk == nullptr) return launch_dma<256, 128, 32, 3>(p, stream);
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 64, 3>(p, stream);
 #endif

@@ -55,6 +55,14 @@ class BucketReducer:
         self.cuda = flat.is_cuda
         self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.world > 1) else None
         self._handles = []
+        # gloo has no device-side collectives: a GPU buffer is staged through pinned host memory by THIS class (explicit
+        # copies on the side stream + gloo's CPU all-reduce) rather than by ProcessGroupGloo's own CUDA path, which hung
+        # intermittently with two ranks on one device.  RCCL ("nccl") reduces in place on the device.
+        self.host_staged = bool(self.cuda and self.world > 1 and dist.get_backend(group) == "gloo")
+        self._pinned = None
+        if self.host_staged:
+            n = max((hi - lo for parts in self.segments for (lo, hi) in parts), default=0)
+            self._pinned = torch.empty(n, dtype=flat.dtype).pin_memory()
 
     def reduce(self, i: int, ready_event: Optional["torch.cuda.Event"] = None) -> None:
         """Start the all-reduce of segment i (after `ready_event` on the side stream when given)."""
@@ -67,7 +75,16 @@ class BucketReducer:
                 self.stream.wait_stream(torch.cuda.current_stream(self.flat.device))
             with torch.cuda.stream(self.stream):
                 for (lo, hi) in self.segments[i]:
-                    if hi > lo:
+                    if hi <= lo:
+                        continue
+                    if self.host_staged:
+                        host = self._pinned[:hi - lo]
+                        host.copy_(self.flat[lo:hi], non_blocking=True)
+                        self.stream.synchronize()
+                        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+                        self.flat[lo:hi].copy_(host, non_blocking=True)
+                        self.stream.synchronize()     # the pinned buffer is reused by the next piece
+                    else:
                         dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         else:
             for (lo, hi) in self.segments[i]:
