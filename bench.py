@@ -212,7 +212,7 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    FC1 = f"fc1 gemm_f32_dma<128,128,32,4> {B}x{fw.FF}x{fw.H} bias+gelu_tanh"
+    FC1 = f"fc1 gemm_f32_dma<256,128,32,3> {B}x{fw.FF}x{fw.H} bias+gelu_tanh"
     kernels = {}
     if rank == 0:
         for name, (M, N, Kd, kw) in {

@@ -297,10 +297,13 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
     float consistency_weight;     /* FLC, :162-165 */
     float enc_recon_weight;       /* AE,  :183-187 */
     float flow_recon_weight;      /* FLD, :174-178 */
+    float enc_contrastive_weight;  /* InfoNCE(obs_latents, action_latents), :134-139 (0 in vita.yaml) */
+    float flow_contrastive_weight; /* InfoNCE(obs_latents, action_latents_pred), :167-172 (0 in vita.yaml) */
+    float temperature;             /* contrastive_loss.py:5 default 0.07; 0 here selects that default */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,
-       VITA_LOSS_COUNT = 8 };
+       VITA_LOSS_ENC_CONTRASTIVE = 5, VITA_LOSS_FLOW_CONTRASTIVE = 6, VITA_LOSS_COUNT = 8 };
 
 /* vita_compute_loss_f32 — VitaPolicy.compute_loss from observer features on (vita_policy.py:112-189, defaults: plain
  * autoencoder, nothing frozen, contrastive weights 0) followed by its backward pass (loss.backward(),
@@ -361,6 +364,23 @@ int vita_generate_actions_bf16(const float* obs_b, int32_t O, const vita_flownet
                                const vita_bf16_weights* bw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
                                float* latents_out, int32_t B, int32_t num_steps, void* workspace, size_t workspace_bytes,
                                vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Optional loss terms (weights 0.0 / non-variational in vita.yaml:18-19,40-41).
+ * --------------------------------------------------------------------------------------- */
+/* compute_contrastive_loss (losses/contrastive_loss.py:5-22): symmetric InfoNCE between a (B,D) and b (B,D):
+ * F.normalize both, logits = a_n.b_n^T / temperature, (CE(logits, arange) + CE(logits^T, arange)) / 2 -> loss (device float).
+ * With gout (device float) the gradients gout[0] * d loss/d a, d b are written to grad_a / grad_b (either may be NULL). */
+size_t vita_contrastive_loss_workspace_bytes(int32_t B, int32_t D);
+int vita_contrastive_loss_f32(const float* a, int64_t lda, const float* b, int64_t ldb, int32_t B, int32_t D, float temperature, float* loss,
+                              const float* gout, float* grad_a, int64_t ld_ga, float* grad_b, int64_t ld_gb, void* workspace,
+                              size_t workspace_bytes, vita_stream_t stream);
+/* DiagonalGaussianDistribution.kl(other=None).mean() (models/dists.py:23-31, vita_policy.py:148):
+ * mean(0.5 * sum_c(mean^2 + exp(logvar) - 1 - logvar)).  row_scratch: B floats. */
+int vita_gaussian_kl_fwd_f32(const float* mean, int64_t ld_mean, const float* logvar, int64_t ld_logvar, int32_t B, int32_t C, float* row_scratch,
+                             float* out, vita_stream_t stream);
+int vita_gaussian_kl_bwd_f32(const float* mean, int64_t ld_mean, const float* logvar, int64_t ld_logvar, int32_t B, int32_t C, const float* gout,
+                             float* grad_mean, int64_t ld_gm, float* grad_logvar, int64_t ld_gv, vita_stream_t stream);
 
 #ifdef __cplusplus
 }

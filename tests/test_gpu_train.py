@@ -219,6 +219,7 @@ def test_sumsq_and_fused_adamw_ema(ops, dev):
 # ----------------------------------------------------------------------------------------
 CASES = ["tiny_A2_cnn", "tiny_A7_cnn", "tiny_A21_cnn", "tiny_A7_simple"]
 LOSS_KEYS = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss")
+LOSS_KEYS_ALL = LOSS_KEYS + ("enc_contrastive_loss", "flow_contrastive_loss")
 
 
 def case_sd(tiny, tag):
@@ -270,7 +271,8 @@ def oracle_grads(sd, obs, actions, t, **kw):
     return m, grads, gs[-1]
 
 
-@pytest.mark.parametrize("variant", ["default", "l2_pairs", "no_decode", "no_cons_no_enc_recon", "k1"])
+@pytest.mark.parametrize("variant", ["default", "l2_pairs", "no_decode", "no_cons_no_enc_recon", "k1", "contrastive", "contrastive_enc_only",
+                                     "contrastive_pairs_no_recon"])
 def test_compute_loss_config_variants_vs_oracle_fp64(ops, dev, variant):
     """Small dims (D=H=64, L=3), every branch of vita_policy.py:153-187, repeated pairing indices."""
     A, T, B = 7, 16, 19
@@ -289,9 +291,18 @@ def test_compute_loss_config_variants_vs_oracle_fp64(ops, dev, variant):
         kw.update(consistency_weight=0.0, enc_recon_weight=0.0); ck.update(consistency_weight=0.0, enc_recon_weight=0.0)
     elif variant == "k1":
         kw.update(num_steps=1); ck.update(num_steps=1)
+    elif variant == "contrastive":          # vita_policy.py:134-139 and :167-172 together
+        kw.update(enc_contrastive_weight=0.3, flow_contrastive_weight=0.2); ck.update(enc_contrastive_weight=0.3, flow_contrastive_weight=0.2)
+    elif variant == "contrastive_enc_only":  # no sampler: the flow term must not be computed even with a weight
+        kw.update(enc_contrastive_weight=0.7, flow_contrastive_weight=0.2, decode_flow_latents=False)
+        ck.update(enc_contrastive_weight=0.7, flow_contrastive_weight=0.2, decode_flow_latents=False)
+    elif variant == "contrastive_pairs_no_recon":
+        pi, pj = torch.randint(0, B, (B,), generator=g), torch.randint(0, B, (B,), generator=g)
+        kw.update(flow_contrastive_weight=1.5, flow_recon_weight=0.0, consistency_weight=0.0, pair_i=pi, pair_j=pj)
+        ck.update(flow_contrastive_weight=1.5, flow_recon_weight=0.0, consistency_weight=0.0)
     m, gref, dobs_ref = oracle_grads(sd, obs, actions, t, **kw)
     losses, grads, dobs = run_fused(ops, dev, sd, obs, actions, t, ops.loss_config(**ck), pair_j=pj, pair_i=pi)
-    for i, k in enumerate(LOSS_KEYS):
+    for i, k in enumerate(LOSS_KEYS_ALL):
         if k in m:
             assert abs(losses[i].item() - m[k].item()) <= 1e-5 * abs(m[k].item()), f"{variant} {k}"
         else:

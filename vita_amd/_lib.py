@@ -87,6 +87,7 @@ class LossConfig(C.Structure):
     _fields_ = [
         ("num_steps", C.c_int32), ("recon_l1", C.c_int32), ("decode_flow_latents", C.c_int32),
         ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
+        ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
     ]
 
 
@@ -100,7 +101,8 @@ class Bf16Weights(C.Structure):
 
 
 ENC_CNN, ENC_SIMPLE = 0, 1
-LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss")
+LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "enc_contrastive_loss",
+              "flow_contrastive_loss")
 LOSS_COUNT = 8
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
@@ -157,6 +159,12 @@ SIGNATURES = {
     "vita_generate_actions_bf16": (C.c_int, [c_fp, C.c_int32, C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
                                              C.POINTER(Bf16Weights), c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int32, C.c_int32,
                                              c_fp, C.c_size_t, c_fp]),
+    "vita_contrastive_loss_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "vita_contrastive_loss_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, c_fp, c_fp, c_fp, C.c_int64,
+                                            c_fp, C.c_int64, c_fp, C.c_size_t, c_fp]),
+    "vita_gaussian_kl_fwd_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, c_fp]),
+    "vita_gaussian_kl_bwd_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int64, c_fp, C.c_int64,
+                                           c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

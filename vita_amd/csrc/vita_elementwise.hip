@@ -264,8 +264,11 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
 #define VITA_LN(NC, ROWS)                                                                                                       \
     hipLaunchKernelGGL((ln_mod_kernel<NC, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps, md, \
                        mul, ld_mul, add, ld_add, vec, ybf, ld_ybf)
-    if (H <= 256) VITA_LN(1, 4);
-    else if (H <= 512) VITA_LN(2, 4);
+#ifndef VITA_LN_ROWS
+#define VITA_LN_ROWS 4
+#endif
+    if (H <= 256) VITA_LN(1, VITA_LN_ROWS);
+    else if (H <= 512) VITA_LN(2, VITA_LN_ROWS);
     else if (H <= 1024) VITA_LN(4, 2);
     else VITA_LN(8, 1);
 #undef VITA_LN

@@ -67,6 +67,27 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                                               int lane, int tid) {
     constexpr int S = BN + 4;
     constexpr int TM = BM / 2, TN = BN / 4;
+    constexpr int C4 = BN / 4;
+    constexpr int ITERS = BM * C4 / NT_;
+    static_assert(BM * C4 % NT_ == 0, "tile / thread-count mismatch");
+    // The residual (and, in the backward GEMMs, the saved pre-activation) rows this thread will combine with are
+    // requested BEFORE the accumulators go through LDS, so their latency overlaps the LDS round trip and the barrier
+    // instead of sitting in front of every store (fc2: epilogue 10.0k -> see DESIGN.md).
+    constexpr bool PREFETCH = ITERS <= 8;
+    f32x4 pre_r[PREFETCH ? ITERS : 1], pre_z[(PREFETCH && BWD) ? ITERS : 1];
+    const bool pf = PREFETCH && e.vec && e.partial == nullptr;
+    if (pf) {
+#pragma unroll
+        for (int it = 0; it < (PREFETCH ? ITERS : 0); ++it) {
+            const int c = tid + it * NT_;
+            const int row = m0 + c / C4, col = n0 + (c % C4) * 4;
+            const bool ok = row < e.M && col + 3 < e.N;
+            if (e.resid != nullptr && ok) pre_r[it] = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+            if constexpr (BWD) {
+                if (ok) pre_z[it] = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+            }
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -82,9 +103,6 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
     const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
     const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
     const bool has_resid = e.resid != nullptr;
-    constexpr int C4 = BN / 4;
-    constexpr int ITERS = BM * C4 / NT_;
-    static_assert(BM * C4 % NT_ == 0, "tile / thread-count mismatch");
     if (e.partial != nullptr) {   // split-K: raw accumulators only (ld_partial is a multiple of 4, the buffer 16-byte aligned)
 #pragma unroll 4
         for (int it = 0; it < ITERS; ++it) {
@@ -96,7 +114,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
         }
         return;
     }
-#pragma unroll 4
+#pragma unroll
     for (int it = 0; it < ITERS; ++it) {
         const int c = tid + it * NT_;
         const int lr = c / C4, lc = (c % C4) * 4;
@@ -106,11 +124,17 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
         if (e.vec && col + 3 < e.N) {
             f32x4 b = {0.f, 0.f, 0.f, 0.f}, zin = b, g = b, rs = b, pre, out;
             if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
-            if constexpr (BWD) zin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+            if constexpr (BWD) {
+                if (pf) zin = pre_z[PREFETCH ? it : 0];
+                else zin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+            }
             if (gate_vec) g = *reinterpret_cast<const f32x4*>(e.gate + col);
             else if (gate_mat) g = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
             else g = f32x4{e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
-            if (has_resid) rs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+            if (has_resid) {
+                if (pf) rs = pre_r[PREFETCH ? it : 0];
+                else rs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+            }
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float p_ = 0.f;

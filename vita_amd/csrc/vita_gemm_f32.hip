@@ -305,7 +305,6 @@ bool gemm_f32_dma_eligible(const vita_linear_args& a);
 
 // ---- split-K: second pass ------------------------------------------------------------------------
 // Y = epilogue( sum_{s=0..S-1} partial[s] ) with the splits added in index order (deterministic).
-constexpr size_t SPLITK_WS_BYTES = size_t(32) << 20;
 constexpr int SPLITK_MAX_TILES = 128;     // split only when a launch would fill at most half of the 256 CUs
 constexpr int SPLITK_MIN_K = 128;         // k elements per split (a multiple of every kernel's BK)
 

@@ -83,6 +83,13 @@ inline int check_ws(const void* ws, size_t have, size_t need, const char* who) {
     return VITA_OK;
 }
 
+// InfoNCE pieces (vita_contrastive.hip): forward keeps what the backward needs in `ws` (nce_workspace_bytes)
+size_t nce_workspace_bytes(int B, int D);
+int nce_forward(const float* a, int64_t lda, const float* b, int64_t ldb, int B, int D, float temperature, float* loss, void* ws, hipStream_t s);
+int nce_backward(int B, int D, float temperature, const float* gout, float* da, int64_t ld_da, int acc_a, float* db, int64_t ld_db, int acc_b,
+                 void* ws, hipStream_t s);
+int launch_axpy(const float* x, float* y, int64_t n, hipStream_t s);   // y += x
+
 int check_flow_weights(const vita_flownet_weights* w, const char* who);
 int check_dec_weights(const vita_decoder_weights* w, const char* who);
 

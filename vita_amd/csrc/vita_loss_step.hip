@@ -382,6 +382,7 @@ struct StepWs {
     float *sk, *consts, *loss_part, *cs_part;
     float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
     float *ut, *vt, *dut, *dxt, *dxa, *dxb;
+    float *nce_enc, *nce_flow, *dz0c;   // InfoNCE state (vita_contrastive.hip) and its d z0, added to dz0 at the end
     FlowTrainWs flow;
     StackWs dec;
     StackWs senc;   // simple encoder
@@ -419,6 +420,10 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
         s.dxa = c.take(B * D);
         s.dxb = c.take(B * D);
     }
+    const bool nce_e = cfg.enc_contrastive_weight > 0.f, nce_f = cfg.decode_flow_latents && cfg.flow_contrastive_weight > 0.f;
+    if (nce_e) s.nce_enc = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
+    if (nce_f) s.nce_flow = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
+    if (train && (nce_e || nce_f)) s.dz0c = c.take(B * D);
     s.flow = carve_flow_train(c, w.flow, B, K, train);
     s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
@@ -486,6 +491,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     VITA_REQUIRE(cfg != nullptr, "%s: null config", who);
     VITA_REQUIRE(!cfg->decode_flow_latents || cfg->num_steps >= 1, "%s: num_steps must be >= 1 (got %d)", who, cfg->num_steps);
     VITA_REQUIRE(cfg->consistency_weight >= 0.f && cfg->enc_recon_weight >= 0.f && cfg->flow_recon_weight >= 0.f, "%s: negative loss weight", who);
+    VITA_REQUIRE(cfg->enc_contrastive_weight >= 0.f && cfg->flow_contrastive_weight >= 0.f && cfg->temperature >= 0.f,
+                 "%s: negative contrastive weight / temperature", who);
     VITA_REQUIRE(B >= 1, "%s: B must be >= 1 (the mean over an empty batch is undefined)", who);
     VITA_REQUIRE(obs_features && actions && t && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/losses", who);
     VITA_REQUIRE(d_obs_features == nullptr || (grads != nullptr && ld_dobs >= w->O), "%s: d_obs_features needs grads and ld_dobs >= O", who);
@@ -507,6 +514,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
     const bool dec_enc = cfg->enc_recon_weight > 0.f;
+    const bool nce_enc = cfg->enc_contrastive_weight > 0.f;
+    const bool nce_flow = do_sample && cfg->flow_contrastive_weight > 0.f;
+    const float tau = cfg->temperature > 0.f ? cfg->temperature : 0.07f;
     const int64_t ldm = (int64_t)L * 3 * H;
     float* pred = s.ZZ;
     float* z1 = s.ZZ + (size_t)B * D;
@@ -514,8 +524,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     SplitkScope skscope(s.sk, kSplitkBytes);
 
     // loss weights as device scalars (seeds of the backward pass) ; zero the outputs
-    const float seeds[4] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight};
-    VITA_TRY(launch_set_scalars(s.consts, seeds, 4, st));
+    const float seeds[6] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight, cfg->enc_contrastive_weight,
+                            cfg->flow_contrastive_weight};
+    VITA_TRY(launch_set_scalars(s.consts, seeds, 6, st));
     VITA_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * VITA_LOSS_COUNT, st));
 
     // ---- forward ------------------------------------------------------------------------------
@@ -529,6 +540,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
     VITA_TRY(flow_eval_fwd(fc, 0, s.flow.mod, ldm, s.vt, D, nullptr, 0, 0.f));
     VITA_TRY(vita_mse_loss_fwd_f32(s.vt, s.ut, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_FLOW, st));
+    if (nce_enc) VITA_TRY(nce_forward(s.z0, D, z1, D, B, D, tau, losses + VITA_LOSS_ENC_CONTRASTIVE, s.nce_enc, st));              // :134-139
     // Euler sampler with grad, vita_policy.py:153-160 / flow_matchers.py:55-79
     const float dt = K > 0 ? (float)(1.0 / (double)K) : 0.f;
     if (do_sample) {
@@ -539,6 +551,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
             VITA_TRY(flow_eval_fwd(fc, e, s.flow.mod + (size_t)(B + k) * ldm, 0, dst, D, fc.X(e), D, dt));
         }
         if (do_cons) VITA_TRY(vita_mse_loss_fwd_f32(pred, z1, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_CONSISTENCY, st));   // :162-165
+        if (nce_flow) VITA_TRY(nce_forward(s.z0, D, pred, D, B, D, tau, losses + VITA_LOSS_FLOW_CONTRASTIVE, s.nce_flow, st));   // :167-172
     }
     // both decoder calls as one batch of rows [r0, r0 + M) of ZZ = [pred; z1]      :174-187
     const Stack dec = stack_of(w->dec);
@@ -552,9 +565,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         if (dec_pred) VITA_TRY(recon(s.dec.out, actions, n_rec, s.loss_part, losses + VITA_LOSS_FLOW_RECON, st));
         if (dec_enc) VITA_TRY(recon(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.loss_part, losses + VITA_LOSS_ENC_RECON, st));
     }
-    const float wsum[5] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
-                           dec_enc ? cfg->enc_recon_weight : 0.f};
-    VITA_TRY(launch_weighted_sum(losses, wsum, 5, losses + VITA_LOSS_TOTAL, st));
+    const float wsum[7] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
+                           dec_enc ? cfg->enc_recon_weight : 0.f, nce_enc ? cfg->enc_contrastive_weight : 0.f,
+                           nce_flow ? cfg->flow_contrastive_weight : 0.f};
+    VITA_TRY(launch_weighted_sum(losses, wsum, 7, losses + VITA_LOSS_TOTAL, st));
     if (!train) return VITA_OK;
 
     // ---- backward -----------------------------------------------------------------------------
@@ -590,6 +604,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     float* dpred = s.dZZ;
     float* dz1 = s.dZZ + (size_t)B * D;
     if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
+    // InfoNCE terms: d pred / d z1 join dZZ now (before the sampler is unrolled); their d z0 waits in dz0c because the
+    // sampler's first step OVERWRITES dz0 below
+    if (nce_flow) VITA_TRY(nce_backward(B, D, tau, s.consts + 5, s.dz0c, D, 0, dpred, D, 1, s.nce_flow, st));
+    if (nce_enc) VITA_TRY(nce_backward(B, D, tau, s.consts + 4, s.dz0c, D, nce_flow ? 1 : 0, dz1, D, 1, s.nce_enc, st));
     // flow-matching evaluation
     VITA_TRY(vita_mse_loss_bwd_f32(s.vt, s.ut, (int64_t)B * D, s.consts + 0, fc.DV(0), s.dut, 0, st));
     VITA_TRY(flow_eval_bwd(fc, 0, s.flow.mod, ldm, s.flow.dmod, s.dxt, D, nullptr, 0));
@@ -608,6 +626,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         VITA_CHECK_HIP(hipMemsetAsync(s.dz0, 0, (size_t)B * D * 4, st));
     }
     VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
+    if (nce_enc || nce_flow) VITA_TRY(launch_axpy(s.dz0c, s.dz0, (int64_t)B * D, st));
     VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
     VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
     VITA_TRY(record(1));

@@ -309,6 +309,53 @@ def mse_loss_bwd(a, b, g, need_a=True, need_b=True): return _loss_bwd("vita_mse_
 def l1_loss_bwd(a, b, g, need_a=True, need_b=True): return _loss_bwd("vita_l1_loss_bwd_f32", a, b, g, need_a, need_b)
 
 
+def contrastive_loss(a: Tensor, b: Tensor, temperature: float = 0.07, gout: Optional[Tensor] = None):
+    """compute_contrastive_loss (losses/contrastive_loss.py:5-22): symmetric InfoNCE.  Returns the loss (0-d device tensor), or
+    (loss, grad_a, grad_b) when `gout` (d objective / d loss) is given."""
+    lib = L.load()
+    a = _rows(a, "contrastive_loss: a")
+    b = _rows(b, "contrastive_loss: b")
+    if a.shape != b.shape:
+        raise L.VitaHipError(f"contrastive_loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    B, D = a.shape
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    ga = gb = None
+    if gout is not None:
+        gout = _f32(gout, "contrastive_loss: gout").reshape(1).contiguous()
+        ga, gb = torch.empty((B, D), dtype=torch.float32, device=a.device), torch.empty((B, D), dtype=torch.float32, device=a.device)
+    nbytes = lib.vita_contrastive_loss_workspace_bytes(B, D)
+    ws = workspace(a.device, nbytes)
+    L.check(lib.vita_contrastive_loss_f32(a.data_ptr(), _ld(a), b.data_ptr(), _ld(b), B, D, float(temperature), out.data_ptr(),
+                                          gout.data_ptr() if gout is not None else None,
+                                          ga.data_ptr() if ga is not None else None, D, gb.data_ptr() if gb is not None else None, D,
+                                          ws.data_ptr(), ws.numel(), _stream(a)), "vita_contrastive_loss_f32")
+    return out if gout is None else (out, ga, gb)
+
+
+def gaussian_kl(params: Tensor, gout: Optional[Tensor] = None):
+    """DiagonalGaussianDistribution(params).kl().mean() (models/dists.py:10-31): params (B, 2C) = [mean | logvar].  With
+    `gout` also returns d/d params."""
+    lib = L.load()
+    params = _rows(params, "gaussian_kl: params")
+    B, C2 = params.shape
+    if C2 % 2:
+        raise L.VitaHipError(f"gaussian_kl: parameters need an even last dim (mean | logvar), got {C2}")
+    Cc = C2 // 2
+    ld = _ld(params)
+    mean_p, logvar_p = params.data_ptr(), params.data_ptr() + 4 * Cc
+    rows = torch.empty(B, dtype=torch.float32, device=params.device)
+    out = torch.empty((), dtype=torch.float32, device=params.device)
+    L.check(lib.vita_gaussian_kl_fwd_f32(mean_p, ld, logvar_p, ld, B, Cc, rows.data_ptr(), out.data_ptr(), _stream(params)),
+            "vita_gaussian_kl_fwd_f32")
+    if gout is None:
+        return out
+    gout = _f32(gout, "gaussian_kl: gout").reshape(1).contiguous()
+    g = torch.empty((B, C2), dtype=torch.float32, device=params.device)
+    L.check(lib.vita_gaussian_kl_bwd_f32(mean_p, ld, logvar_p, ld, B, Cc, gout.data_ptr(), g.data_ptr(), C2, g.data_ptr() + 4 * Cc, C2,
+                                         _stream(params)), "vita_gaussian_kl_bwd_f32")
+    return out, g
+
+
 def _idx(t, device):
     return None if t is None else t.to(device=device, dtype=torch.int64).contiguous()
 
@@ -652,12 +699,14 @@ class PolicyHandle:
 
 
 def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
-                enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5) -> "L.LossConfig":
+                enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, enc_contrastive_weight: float = 0.0,
+                flow_contrastive_weight: float = 0.0, temperature: float = 0.07) -> "L.LossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")   # vita_policy.py:71
     c = L.LossConfig()
     c.num_steps, c.recon_l1, c.decode_flow_latents = num_steps, int(recon == "l1"), int(decode_flow_latents)
     c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
+    c.enc_contrastive_weight, c.flow_contrastive_weight, c.temperature = enc_contrastive_weight, flow_contrastive_weight, temperature
     return c
 
 

@@ -234,7 +234,6 @@ class VitaPolicy(nn.Module):
         unsupported = []
         if self.use_action_vae: unsupported.append("action_ae.use_variational")
         if self.freeze_action_encoder or self.freeze_action_decoder: unsupported.append("action_ae.freeze_*")
-        if self.enc_contrastive_weight > 0 or self.flow_contrastive_weight > 0: unsupported.append("vita.*_contrastive_weight > 0")
         if unsupported:
             raise NotImplementedError("non-default branches outside this build's fused training path: " + ", ".join(unsupported))
         self.obs_encoder = nn.Linear(self.obs_dim, self.latent_dim)                                      # :77
@@ -252,7 +251,9 @@ class VitaPolicy(nn.Module):
                                          decode_flow_latents=bool(pol.vita.decode_flow_latents),
                                          consistency_weight=float(pol.vita.consistency_weight),
                                          enc_recon_weight=float(self.enc_action_recon_weight),
-                                         flow_recon_weight=float(self.flow_action_recon_weight))
+                                         flow_recon_weight=float(self.flow_action_recon_weight),
+                                         enc_contrastive_weight=float(self.enc_contrastive_weight),
+                                         flow_contrastive_weight=float(self.flow_contrastive_weight))
         # GEMM operand type for INFERENCE: "f32" (default: the reference's strict-fp32 numerics) or "bf16" (bf16 MFMA operands,
         # fp32 accumulate; stated tolerance 2e-2 on the actions).  Not a reference key: policy.gemm_dtype.
         self.gemm_dtype = str(pol.get("gemm_dtype", "f32"))
@@ -403,9 +404,13 @@ class VitaPolicy(nn.Module):
         vals = losses.detach().cpu().tolist()
         metrics = {"loss": vals[1], "flow_loss": vals[1]}   # FM.compute_loss's own 'loss' entry is the flow loss (flow_matchers.py:39)
         cfgv = self.config.policy.vita
+        if self.enc_contrastive_weight > 0:
+            metrics["enc_contrastive_loss"] = vals[5]
         if cfgv.decode_flow_latents:
             if cfgv.consistency_weight > 0:
                 metrics["consistency_loss"] = vals[2]
+            if self.flow_contrastive_weight > 0:
+                metrics["flow_contrastive_loss"] = vals[6]
             if self.flow_action_recon_weight > 0:
                 metrics["flow_action_recon_loss"] = vals[3]
         if self.enc_action_recon_weight > 0:
