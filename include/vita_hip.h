@@ -300,6 +300,9 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
     float enc_contrastive_weight;  /* InfoNCE(obs_latents, action_latents), :134-139 (0 in vita.yaml) */
     float flow_contrastive_weight; /* InfoNCE(obs_latents, action_latents_pred), :167-172 (0 in vita.yaml) */
     float temperature;             /* contrastive_loss.py:5 default 0.07; 0 here selects that default */
+    int32_t freeze_encoder;        /* action_ae.freeze_encoder: action latents carry no gradient (:119), no sampler branch (:153) */
+    int32_t freeze_decoder;        /* action_ae.freeze_decoder: no reconstruction terms (:174,183), no sampler branch (:153);
+                                      frozen modules' gradient buffers are written as zeros */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,

@@ -277,16 +277,20 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
                  consistency_weight: float = 1.0, enc_recon_weight: float = 0.5,
                  flow_recon_weight: float = 0.5, recon_loss_type: str = "l1",
                  enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
-                 decode_flow_latents: bool = True, sigma: float = 0.0):
+                 decode_flow_latents: bool = True, sigma: float = 0.0,
+                 freeze_encoder: bool = False, freeze_decoder: bool = False):
     """VitaPolicy.compute_loss, vita_policy.py:112-189, from observer features on, with the
-    default non-variational, non-frozen autoencoder.  Returns (loss, metrics) where metrics
-    holds 0-dim tensors (the reference calls .item() on each)."""
+    default non-variational autoencoder and the freeze flags of :119,142-143,153,174,183.
+    Returns (loss, metrics) where metrics holds 0-dim tensors (the reference calls .item()
+    on each)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
     T, A = gt_actions.shape[1], gt_actions.shape[2]
     B = obs_features.shape[0]
     m = {}
     obs_latents = obs_encode(sd, obs_features)                                  # :114
     action_latents = action_encode(sd, gt_actions)                              # :123
+    if freeze_encoder:                                                          # :119 torch.no_grad()
+        action_latents = action_latents.detach()
     flow_loss = fm_loss(sd, obs_latents, action_latents, t, pair_i, pair_j, sigma)  # :126-130
     loss = flow_loss
     m["flow_loss"] = flow_loss
@@ -294,7 +298,10 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
         c = contrastive_loss(obs_latents.view(B, -1), action_latents.view(B, -1))
         loss = loss + enc_contrastive_weight * c
         m["enc_contrastive_loss"] = c
-    if decode_flow_latents:                                                     # :153-178
+    if freeze_encoder and freeze_decoder:                                       # :142-143
+        m["loss"] = loss
+        return loss, m
+    if decode_flow_latents and not freeze_encoder and not freeze_decoder:       # :153-178
         pred = euler_sample(sd, obs_latents, num_steps)
         if consistency_weight > 0:
             c = F.mse_loss(pred, action_latents)
@@ -304,11 +311,11 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
             c = contrastive_loss(obs_latents.view(B, -1), pred.view(B, -1))
             loss = loss + flow_contrastive_weight * c
             m["flow_contrastive_loss"] = c
-        if flow_recon_weight > 0:
+        if flow_recon_weight > 0 and not freeze_decoder:                        # :174
             r = recon(simple_action_decode(sd, pred, T, A), gt_actions)
             m["flow_action_recon_loss"] = r
             loss = loss + flow_recon_weight * r
-    if enc_recon_weight > 0:                                                    # :183-187
+    if enc_recon_weight > 0 and not freeze_decoder:                             # :183-187
         r = recon(simple_action_decode(sd, action_latents, T, A), gt_actions)
         m["enc_action_recon_loss"] = r
         loss = loss + enc_recon_weight * r

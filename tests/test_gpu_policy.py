@@ -208,6 +208,47 @@ def test_trainer_steps_match_the_reference_step_restated_on_cpu(tmp_path):
     assert set(sd1) == set(sd2) and all(torch.equal(sd1[k], sd2[k]) for k in sd1)
 
 
+def test_freeze_flags_and_contrastive_terms_at_policy_level():
+    """action_ae.freeze_encoder (vita_policy.py:119,153) with the contrastive weights on: metric keys as the reference emits
+    them, frozen module without gradient under the autograd bridge, and untouched bit-for-bit by the native trainer."""
+    cfg = small_cfg()
+    cfg.policy.action_ae.freeze_encoder = True
+    cfg.policy.vita.enc_contrastive_weight = 0.25
+    cfg.policy.vita.flow_contrastive_weight = 0.25          # inactive: the sampler branch is gated off by the freeze
+    pol = make_policy(cfg).to(DEV)
+    g = torch.Generator().manual_seed(12)
+    B = 13
+    batch = make_batch(cfg, B, g)
+    t = torch.rand(B, generator=g)
+    nb = pol.normalize_targets(pol.normalize_inputs({k: v.to(DEV) for k, v in batch.items()}))
+    pol.train()
+    loss, metrics = pol.compute_loss(nb, t=t.to(DEV))
+    assert set(metrics) == {"loss", "flow_loss", "enc_contrastive_loss", "enc_action_recon_loss"}
+    loss.backward()
+    feats, acts = oracle_features(pol, batch, cfg)
+    sd = {k: v.double().requires_grad_(True) for k, v in hot_sd(pol).items()}
+    rloss, rm = O.compute_loss(sd, feats.double(), acts.double(), t.double(), 6, freeze_encoder=True, enc_contrastive_weight=0.25,
+                               flow_contrastive_weight=0.25)
+    rloss.backward()
+    assert abs(loss.item() - rloss.item()) <= 1e-5 * abs(rloss.item())
+    assert abs(metrics["enc_contrastive_loss"] - rm["enc_contrastive_loss"].item()) <= 1e-5 * rm["enc_contrastive_loss"].item()
+    for k, p in pol.hot_path_named_parameters():
+        if k.startswith("action_encoder."):
+            assert p.grad is None and sd[k].grad is None, k
+        else:
+            assert nerr(p.grad, sd[k].grad) <= 2e-5, k
+    # native trainer: the frozen encoder is skipped by the fused optimizer (no weight decay, no moment update)
+    pol2 = make_policy(cfg)
+    tr = PolicyTrainer(cfg, pol2, DEV, num_training_steps=10)
+    before = {k: p.detach().clone() for k, p in pol2.hot_path_named_parameters()}
+    tr.train_step({k: v.clone() for k, v in batch.items()}, t=t.to(DEV))
+    m = tr.metrics()
+    assert abs(m["loss"] - rloss.item()) <= 1e-5 * abs(rloss.item()) and m["flow_contrastive_loss"] == 0.0
+    for k, p in pol2.hot_path_named_parameters():
+        same = torch.equal(p.detach(), before[k])
+        assert same == k.startswith("action_encoder."), k
+
+
 def test_full_size_training_step_properties_b4096():
     """hook_package dims at B = 4096 per GPU (the large-batch data-parallel regime): finite, deterministic, and the
     gradient of a batch equals the mean of the gradients of its two halves (what the all-reduce relies on)."""

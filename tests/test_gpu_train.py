@@ -272,7 +272,7 @@ def oracle_grads(sd, obs, actions, t, **kw):
 
 
 @pytest.mark.parametrize("variant", ["default", "l2_pairs", "no_decode", "no_cons_no_enc_recon", "k1", "contrastive", "contrastive_enc_only",
-                                     "contrastive_pairs_no_recon"])
+                                     "contrastive_pairs_no_recon", "freeze_encoder", "freeze_decoder", "freeze_both_contrastive"])
 def test_compute_loss_config_variants_vs_oracle_fp64(ops, dev, variant):
     """Small dims (D=H=64, L=3), every branch of vita_policy.py:153-187, repeated pairing indices."""
     A, T, B = 7, 16, 19
@@ -300,6 +300,13 @@ def test_compute_loss_config_variants_vs_oracle_fp64(ops, dev, variant):
         pi, pj = torch.randint(0, B, (B,), generator=g), torch.randint(0, B, (B,), generator=g)
         kw.update(flow_contrastive_weight=1.5, flow_recon_weight=0.0, consistency_weight=0.0, pair_i=pi, pair_j=pj)
         ck.update(flow_contrastive_weight=1.5, flow_recon_weight=0.0, consistency_weight=0.0)
+    elif variant == "freeze_encoder":        # :119 no grad into the encoder, :153 no sampler, decoder still trained on dec(z1)
+        kw.update(freeze_encoder=True); ck.update(freeze_encoder=True)
+    elif variant == "freeze_decoder":        # :153,174,183: flow loss only, the encoder still gets the flow gradient
+        kw.update(freeze_decoder=True); ck.update(freeze_decoder=True)
+    elif variant == "freeze_both_contrastive":   # :142-143 early return after the flow + encoder-contrastive terms
+        kw.update(freeze_encoder=True, freeze_decoder=True, enc_contrastive_weight=0.4, flow_contrastive_weight=0.4)
+        ck.update(freeze_encoder=True, freeze_decoder=True, enc_contrastive_weight=0.4, flow_contrastive_weight=0.4)
     m, gref, dobs_ref = oracle_grads(sd, obs, actions, t, **kw)
     losses, grads, dobs = run_fused(ops, dev, sd, obs, actions, t, ops.loss_config(**ck), pair_j=pj, pair_i=pi)
     for i, k in enumerate(LOSS_KEYS_ALL):

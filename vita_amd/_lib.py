@@ -88,6 +88,7 @@ class LossConfig(C.Structure):
         ("num_steps", C.c_int32), ("recon_l1", C.c_int32), ("decode_flow_latents", C.c_int32),
         ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
+        ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
     ]
 
 

@@ -403,7 +403,8 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     Carver c(ws);
     StepWs s{};
     const size_t D = w.flow.D;
-    const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0;
+    const bool samples = cfg.decode_flow_latents && !cfg.freeze_encoder && !cfg.freeze_decoder;   // vita_policy.py:153
+    const size_t K = samples ? (size_t)cfg.num_steps : 0;
     s.sk = c.take(kSplitkBytes / sizeof(float));
     s.consts = c.take(16);
     s.loss_part = c.take((size_t)vita_loss_partials_count());
@@ -420,7 +421,7 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
         s.dxa = c.take(B * D);
         s.dxb = c.take(B * D);
     }
-    const bool nce_e = cfg.enc_contrastive_weight > 0.f, nce_f = cfg.decode_flow_latents && cfg.flow_contrastive_weight > 0.f;
+    const bool nce_e = cfg.enc_contrastive_weight > 0.f, nce_f = samples && cfg.flow_contrastive_weight > 0.f;
     if (nce_e) s.nce_enc = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
     if (nce_f) s.nce_flow = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
     if (train && (nce_e || nce_f)) s.dz0c = c.take(B * D);
@@ -457,6 +458,26 @@ int check_policy(const vita_policy_weights* w, const char* who) {
                  w->dec.D, w->enc.D);
     VITA_REQUIRE(w->dec.OUT == w->enc.T * w->enc.A, "%s: decoder OUT=%d != T*A=%d", who, w->dec.OUT, w->enc.T * w->enc.A);
     VITA_REQUIRE(w->flow.H <= 2048, "%s: training supports hidden_dim <= 2048 (got %d)", who, w->flow.H);
+    return VITA_OK;
+}
+
+int zero_encoder_grads(const vita_encoder_weights& g, hipStream_t st) {
+    auto z = [&](const float* p, size_t n) -> int {
+        VITA_CHECK_HIP(hipMemsetAsync(mut(p), 0, n * sizeof(float), st));
+        return VITA_OK;
+    };
+    if (g.kind == VITA_ENC_SIMPLE) {
+        VITA_TRY(z(g.proj_w, (size_t)g.C * g.A)); VITA_TRY(z(g.proj_b, (size_t)g.C));
+        for (int i = 0; i < g.NL; ++i) {
+            VITA_TRY(z(g.w1[i], (size_t)4 * g.C * g.C)); VITA_TRY(z(g.b1[i], (size_t)4 * g.C));
+            VITA_TRY(z(g.w2[i], (size_t)4 * g.C * g.C)); VITA_TRY(z(g.b2[i], (size_t)g.C));
+        }
+    } else {
+        for (int i = 0; i < g.NL; ++i) {
+            VITA_TRY(z(g.w1[i], (size_t)g.C * (i == 0 ? g.A : g.C) * 5)); VITA_TRY(z(g.b1[i], (size_t)g.C));
+        }
+        VITA_TRY(z(g.proj_w, (size_t)g.D * g.C * (g.T >> g.NL))); VITA_TRY(z(g.proj_b, (size_t)g.D));
+    }
     return VITA_OK;
 }
 
@@ -508,12 +529,13 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     const bool train = grads != nullptr;
     StepWs s = carve_step(workspace, *w, *cfg, (size_t)B, true);
     const int D = w->flow.D, H = w->flow.H, L = w->flow.L, OUT = w->dec.OUT;
-    const bool do_sample = cfg->decode_flow_latents != 0;
+    const bool fe = cfg->freeze_encoder != 0, fd = cfg->freeze_decoder != 0;
+    const bool do_sample = cfg->decode_flow_latents != 0 && !fe && !fd;                                                // :153
     const int K = do_sample ? cfg->num_steps : 0;
     const int T = B + K;
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
-    const bool dec_enc = cfg->enc_recon_weight > 0.f;
+    const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd;                                                           // :183
     const bool nce_enc = cfg->enc_contrastive_weight > 0.f;
     const bool nce_flow = do_sample && cfg->flow_contrastive_weight > 0.f;
     const float tau = cfg->temperature > 0.f ? cfg->temperature : 0.07f;
@@ -631,7 +653,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
     VITA_TRY(record(1));
     // encoders
-    if (w->enc.kind == VITA_ENC_SIMPLE) {
+    if (fe) {   // :119 the action latents were computed without grad
+        VITA_TRY(zero_encoder_grads(g.enc, st));
+    } else if (w->enc.kind == VITA_ENC_SIMPLE) {
         VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
                            w->enc.C, nullptr, 0, s.cs_part, st));
     } else {

@@ -700,13 +700,15 @@ class PolicyHandle:
 
 def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
                 enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, enc_contrastive_weight: float = 0.0,
-                flow_contrastive_weight: float = 0.0, temperature: float = 0.07) -> "L.LossConfig":
+                flow_contrastive_weight: float = 0.0, temperature: float = 0.07, freeze_encoder: bool = False,
+                freeze_decoder: bool = False) -> "L.LossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")   # vita_policy.py:71
     c = L.LossConfig()
     c.num_steps, c.recon_l1, c.decode_flow_latents = num_steps, int(recon == "l1"), int(decode_flow_latents)
     c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
     c.enc_contrastive_weight, c.flow_contrastive_weight, c.temperature = enc_contrastive_weight, flow_contrastive_weight, temperature
+    c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
     return c
 
 

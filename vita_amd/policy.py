@@ -178,7 +178,8 @@ class _FusedLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, *params):
         pw, gw, gsd = policy._train_handles(stage=True)
-        staged = [gsd[k] for k, _ in policy.hot_path_named_parameters()]
+        frozen = policy.frozen_prefixes()
+        staged = [None if k.startswith(frozen) else gsd[k] for k, _ in policy.hot_path_named_parameters()]
         need_dobs = obs_features.requires_grad
         losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
                                         need_dobs=need_dobs)
@@ -188,7 +189,7 @@ class _FusedLoss(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout, _):
-        grads = tuple(g * gout for g in ctx.staged)
+        grads = tuple((g * gout if g is not None else None) for g in ctx.staged)
         dobs = ctx.dobs * gout if ctx.dobs is not None else None
         return (None, dobs, None, None, None, None) + grads
 
@@ -233,7 +234,6 @@ class VitaPolicy(nn.Module):
         self.flow_contrastive_weight = pol.vita.flow_contrastive_weight
         unsupported = []
         if self.use_action_vae: unsupported.append("action_ae.use_variational")
-        if self.freeze_action_encoder or self.freeze_action_decoder: unsupported.append("action_ae.freeze_*")
         if unsupported:
             raise NotImplementedError("non-default branches outside this build's fused training path: " + ", ".join(unsupported))
         self.obs_encoder = nn.Linear(self.obs_dim, self.latent_dim)                                      # :77
@@ -253,7 +253,9 @@ class VitaPolicy(nn.Module):
                                          enc_recon_weight=float(self.enc_action_recon_weight),
                                          flow_recon_weight=float(self.flow_action_recon_weight),
                                          enc_contrastive_weight=float(self.enc_contrastive_weight),
-                                         flow_contrastive_weight=float(self.flow_contrastive_weight))
+                                         flow_contrastive_weight=float(self.flow_contrastive_weight),
+                                         freeze_encoder=bool(self.freeze_action_encoder),
+                                         freeze_decoder=bool(self.freeze_action_decoder))
         # GEMM operand type for INFERENCE: "f32" (default: the reference's strict-fp32 numerics) or "bf16" (bf16 MFMA operands,
         # fp32 accumulate; stated tolerance 2e-2 on the actions).  Not a reference key: policy.gemm_dtype.
         self.gemm_dtype = str(pol.get("gemm_dtype", "f32"))
@@ -273,6 +275,29 @@ class VitaPolicy(nn.Module):
             for k, p in named.items():
                 if k.startswith(prefixes) and p.requires_grad:
                     out.append((k, p))
+        return out
+
+    def frozen_prefixes(self) -> tuple:
+        """Modules that receive no gradient under the freeze flags (vita_policy.py:119,153,174,183): the reference leaves
+        their .grad at None, so its optimizer skips them."""
+        out = []
+        if self.freeze_action_encoder:
+            out.append("action_encoder.")
+        if self.freeze_action_decoder:
+            out.append("action_decoder.")
+        return tuple(out) if out else ("\0",)
+
+    def trainable_ranges(self):
+        """Element ranges of the flat buffers the optimizer updates (everything but the frozen modules), merged."""
+        frozen, off, out = self.frozen_prefixes(), 0, []
+        for k, p in self.hot_path_named_parameters():
+            n = p.numel()
+            if not k.startswith(frozen):
+                if out and out[-1][1] == off:
+                    out[-1] = (out[-1][0], off + n)
+                else:
+                    out.append((off, off + n))
+            off += n
         return out
 
     def flatten_parameters(self):
@@ -406,14 +431,15 @@ class VitaPolicy(nn.Module):
         cfgv = self.config.policy.vita
         if self.enc_contrastive_weight > 0:
             metrics["enc_contrastive_loss"] = vals[5]
-        if cfgv.decode_flow_latents:
+        fe, fd = self.freeze_action_encoder, self.freeze_action_decoder
+        if cfgv.decode_flow_latents and not fe and not fd:
             if cfgv.consistency_weight > 0:
                 metrics["consistency_loss"] = vals[2]
             if self.flow_contrastive_weight > 0:
                 metrics["flow_contrastive_loss"] = vals[6]
             if self.flow_action_recon_weight > 0:
                 metrics["flow_action_recon_loss"] = vals[3]
-        if self.enc_action_recon_weight > 0:
+        if self.enc_action_recon_weight > 0 and not fd:
             metrics["enc_action_recon_loss"] = vals[4]
         return loss, metrics
 

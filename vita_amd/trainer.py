@@ -39,6 +39,7 @@ class PolicyTrainer:
         self.exp_avg_sq = torch.zeros_like(self.flat)
         self.ema = self.flat.clone() if config.use_ema else None                    # base_policy.py:45-49
         self.rank, self.world = world_info(group)
+        self.update_ranges = policy.trainable_ranges()    # frozen modules are skipped by the optimizer, as torch skips grad=None
         self.reducer = BucketReducer(self.flat_grad, policy.bucket_ranges, group, max_bucket_elems)
         self.overlap = overlap
         self.events = None
@@ -81,10 +82,12 @@ class PolicyTrainer:
         scale = self.reducer.finish()
         ops.sumsq(self.flat_grad, out=self.gnorm_sq)
         step = self.step_counter + 1
-        ops.adamw_ema_step(self.flat, self.flat_grad, self.exp_avg, self.exp_avg_sq, self.ema, step=step, lr=self.current_lr(),
-                           betas=tuple(c.optimizer_betas), eps=c.optimizer_eps, weight_decay=c.optimizer_weight_decay,
-                           gnorm_sq=self.gnorm_sq, max_norm=float(c.train.grad_clip_norm), grad_scale=scale,
-                           ema_decay=ema_decay(step) if self.ema is not None else 0.0)
+        for a, b in self.update_ranges:
+            ops.adamw_ema_step(self.flat[a:b], self.flat_grad[a:b], self.exp_avg[a:b], self.exp_avg_sq[a:b],
+                               self.ema[a:b] if self.ema is not None else None, step=step, lr=self.current_lr(),
+                               betas=tuple(c.optimizer_betas), eps=c.optimizer_eps, weight_decay=c.optimizer_weight_decay,
+                               gnorm_sq=self.gnorm_sq, max_norm=float(c.train.grad_clip_norm), grad_scale=scale,
+                               ema_decay=ema_decay(step) if self.ema is not None else 0.0)
         self.step_counter = step
         self.update_s = time.perf_counter() - t0
         return self.losses
