@@ -270,10 +270,13 @@ def test_full_size_hook_package_b4096(ops, dev):
     idx = torch.cat([torch.arange(0, 8), torch.arange(2040, 2056), torch.arange(4088, 4096)])
     ref = O.generate_actions(sd, obs[idx], K, 16, A).reshape(len(idx), -1)
     close(acts[idx.to(dev)], ref, TOL, "B=4096 sample rows")
-    # (2) row independence / tiling invariance: a sub-batch on the same kernel path gives bitwise the same rows; a small
-    #     one (which takes the split-K path: different summation order) agrees to fp32 rounding
+    # (2) row independence: the same rows at other positions of a batch of the same size (same kernels, other tiles and
+    #     other workgroups) come out bitwise identical; sub-batches of other sizes select other tile shapes / k-splits
+    #     (a different summation order) and agree to fp32 rounding
+    rolled = ops.generate_actions(ow, ob, fw, dw, torch.roll(obs, 1000, 0).to(dev), K)
+    assert torch.equal(torch.roll(rolled, -1000, 0), acts), "rows depend on their position in the batch"
     sub = ops.generate_actions(ow, ob, fw, dw, obs[1000:4000].to(dev), K)
-    assert torch.equal(sub, acts[1000:4000]), "rows depend on their position in the batch"
+    close(sub, acts[1000:4000], 2e-6, "3000-row sub-batch (other tile shapes)")
     small = ops.generate_actions(ow, ob, fw, dw, obs[1000:1100].to(dev), K)
     close(small, acts[1000:1100], 2e-6, "small sub-batch (split-K path)")
     assert torch.equal(small, ops.generate_actions(ow, ob, fw, dw, obs[1000:1100].to(dev), K)), "split-K path not deterministic"

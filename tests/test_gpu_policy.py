@@ -260,17 +260,26 @@ def test_full_size_training_step_properties_b4096():
     pw = ops.PolicyHandle(sd, DEV, strict=True)
     cfgl = ops.loss_config(6)
 
-    def run(sl):
+    def run(sl, cfg=cfgl):
         gsd = {k: torch.empty_like(v) for k, v in sd.items()}
         gw = ops.PolicyHandle(gsd, DEV, strict=True)
-        losses, _ = ops.compute_loss(pw, cfgl, obs[sl], acts[sl], t[sl], grads=gw)
+        losses, _ = ops.compute_loss(pw, cfg, obs[sl], acts[sl], t[sl], grads=gw)
         return losses.clone(), gsd
     l_all, g_all = run(slice(0, B))
     l_again, g_again = run(slice(0, B))
     assert torch.isfinite(l_all[:5]).all() and torch.equal(l_all, l_again)
     assert all(torch.equal(g_all[k], g_again[k]) for k in sd)
-    l_a, g_a = run(slice(0, B // 2))
-    l_b, g_b = run(slice(B // 2, B))
+    # additivity, with the smooth (l2) reconstruction loss: half batches select other tile shapes (another k-summation
+    # order -> last-bit differences in the forward), and at a kink a last-bit difference flips a derivative: under l1 one
+    # sign(d) flip at d ~ 0 moves a 1.4 M-term random-sign sum by ~1e-3.  The conv encoder's ReLUs have the same kink
+    # (one flipped mask bit among 16.7 M pre-activations changes one of the 32768 terms of a weight-gradient row), so the
+    # conv weights are held to 5e-3 and everything behind smooth activations to 2e-5.
+    cfg2 = ops.loss_config(6, recon="l2")
+    l_all, g_all = run(slice(0, B), cfg2)
+    l_a, g_a = run(slice(0, B // 2), cfg2)
+    l_b, g_b = run(slice(B // 2, B), cfg2)
     assert abs((l_a[0] + l_b[0]).item() / 2 - l_all[0].item()) <= 1e-5 * abs(l_all[0].item())
-    worst = max((nerr((g_a[k] + g_b[k]) * 0.5, g_all[k]), k) for k in sd)
+    worst = max((nerr((g_a[k] + g_b[k]) * 0.5, g_all[k]), k) for k in sd if not k.startswith("action_encoder.encoder."))
     assert worst[0] <= 2e-5, worst
+    worst = max((nerr((g_a[k] + g_b[k]) * 0.5, g_all[k]), k) for k in sd if k.startswith("action_encoder.encoder."))
+    assert worst[0] <= 5e-3, worst

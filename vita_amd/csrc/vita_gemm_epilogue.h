@@ -62,11 +62,14 @@ __device__ __forceinline__ float epi_elem(float acc, float bias, float zin, floa
 }
 
 // obuf: at least BM * (BN + 4) floats of LDS that no wave reads any more (caller barriers before the call).
-template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD>
+// KG > 1: the workgroup's waves form KG groups that each reduced a slice of every k-tile over the SAME output tile
+// (in-workgroup split-K); group kg parks its partial tile in region kg of obuf and the row phase sums the regions in
+// index order (deterministic).  obuf then needs KG * BM * (BN + 4) floats.
+template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD, int KG = 1>
 __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
-                                              int lane, int tid) {
+                                              int lane, int tid, int kg = 0) {
     constexpr int S = BN + 4;
-    constexpr int TM = BM / 2, TN = BN / 4;
+    constexpr int TM = MI * 32, TN = NI * 32;
     constexpr int C4 = BN / 4;
     constexpr int ITERS = BM * C4 / NT_;
     static_assert(BM * C4 % NT_ == 0, "tile / thread-count mismatch");
@@ -96,9 +99,19 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
             for (int r = 0; r < 16; ++r) {
                 const int row = wm * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int col = wn * TN + j * 32 + (lane & 31);
-                obuf[row * S + col] = acc[i][j][r];
+                obuf[kg * (BM * S) + row * S + col] = acc[i][j][r];
             }
     __syncthreads();
+    auto tile_row4 = [&](int lr, int lc) -> f32x4 {
+        f32x4 a = *reinterpret_cast<const f32x4*>(obuf + lr * S + lc);
+#pragma unroll
+        for (int g = 1; g < KG; ++g) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(obuf + g * (BM * S) + lr * S + lc);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a[k] += b[k];
+        }
+        return a;
+    };
     const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
     const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
     const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
@@ -110,7 +123,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
             const int lr = c / C4, lc = (c % C4) * 4;
             const int row = m0 + lr, col = n0 + lc;
             if (row >= e.M || col >= e.N) continue;
-            *reinterpret_cast<f32x4*>(e.partial + (int64_t)row * e.ld_partial + col) = *reinterpret_cast<const f32x4*>(obuf + lr * S + lc);
+            *reinterpret_cast<f32x4*>(e.partial + (int64_t)row * e.ld_partial + col) = tile_row4(lr, lc);
         }
         return;
     }
@@ -120,7 +133,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
         const int lr = c / C4, lc = (c % C4) * 4;
         const int row = m0 + lr, col = n0 + lc;
         if (row >= e.M || col >= e.N) continue;
-        const f32x4 a = *reinterpret_cast<const f32x4*>(obuf + lr * S + lc);
+        const f32x4 a = tile_row4(lr, lc);
         if (e.vec && col + 3 < e.N) {
             f32x4 b = {0.f, 0.f, 0.f, 0.f}, zin = b, g = b, rs = b, pre, out;
             if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
@@ -171,12 +184,12 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
 
 // run-time activation -> compile-time dispatch.  BACKWARD = false: forward GEMMs (act = the activation applied);
 // BACKWARD = true: the transposed-operand GEMMs (act = the activation whose derivative is applied from act_grad_z).
-template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD>
+template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD, int KG = 1>
 __device__ __forceinline__ void epilogue_dispatch(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
-                                                  int lane, int tid) {
-#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD>(acc, obuf, e, m0, n0, wm, wn, lane, tid)
+                                                  int lane, int tid, int kg = 0) {
+#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg)
     if (e.partial != nullptr || (BACKWARD && e.act_grad_z == nullptr)) {
-        epilogue_tile<BM, BN, MI, NI, NT_, VITA_ACT_NONE, false>(acc, obuf, e, m0, n0, wm, wn, lane, tid);
+        epilogue_tile<BM, BN, MI, NI, NT_, VITA_ACT_NONE, false, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg);
         return;
     }
     switch (e.act) {

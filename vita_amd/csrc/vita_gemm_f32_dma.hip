@@ -97,18 +97,23 @@ __device__ __forceinline__ int swz(int r) {
 // BF16: the operand bytes are bf16 (p.K / p.ldx / p.ldw count 4-byte units = bf16 pairs, BK 4-byte units = 2*BK bf16 of
 // reduction): same DMA / LDS image, and the 16-byte fragment a lane reads IS the 8-deep bf16 operand of one
 // v_mfma_f32_32x32x16_bf16 (lanes 0-31: k 0-7, lanes 32-63: k 8-15), so one MFMA replaces the four fp32 ones.
-template <int BM, int BN, int BK, int NS, bool LN, int OCC, bool BF16 = false>
+// KG: in-workgroup split-K.  The 8 waves form KG groups of 8/KG; every group covers the WHOLE output tile (so a wave owns
+// KG times more of it: 64x64 instead of 32x32 at 64x128 / KG=4 -> half the LDS fragment reads per MFMA, which is what
+// bounds the small tile) and reduces 1/KG of each k-tile's chunks; the epilogue sums the groups through LDS.
+template <int BM, int BN, int BK, int NS, bool LN, int OCC, bool BF16 = false, int KG = 1>
 __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p) {
     constexpr int CH = BK / 4;                 // 16-byte chunks per tile row
     constexpr int RPI = 64 / CH;               // rows covered by one DMA wave-instruction
     constexpr int A_DMA = BM / RPI / 8;        // DMA instructions per wave per tile (A)
     constexpr int B_DMA = BN / RPI / 8;
     constexpr int DPT = A_DMA + B_DMA;
-    constexpr int TM = BM / 2, TN = BN / 4;
+    constexpr int WGN = KG == 1 ? 4 : 2, WGM = 8 / KG / WGN;   // waves of one k-group along n / m
+    constexpr int TM = BM / WGM, TN = BN / WGN;
     constexpr int MI = TM / 32, NI = TN / 32;
-    constexpr int NCH = BK / 8;
+    constexpr int NCH = BK / 8 / KG;           // 8-deep k chunks of a k-tile that one wave reduces
     constexpr int STAGE = (BM + BN) * BK;      // floats per stage
-    static_assert(A_DMA >= 1 && B_DMA >= 1 && MI >= 1 && NI >= 1 && NCH % 2 == 0 && NS >= 3, "bad tile");
+    static_assert(A_DMA >= 1 && B_DMA >= 1 && MI >= 1 && NI >= 1 && NCH >= 2 && NCH % 2 == 0 && NS >= 3 && WGM >= 1, "bad tile");
+    static_assert(KG == 1 || KG * BM * (BN + 4) <= NS * STAGE, "the k-groups' partial tiles must fit the stage buffers");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [NS][ A: BM x BK | B: BN x BK ]  then (LN only) mul[K], add[K], stats[BM][2]
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 2, wn = wave & 3;
+    const int kg = wave / (WGM * WGN);
+    const int wm = (wave % (WGM * WGN)) / WGN, wn = wave % WGN;
 
     const int nwg = p.tiles_m * p.tiles_n;
     const int split = p.sk_splits > 1 ? (int)blockIdx.x / nwg : 0;
@@ -276,7 +282,7 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     f32x4 af[2][MI], bf[2][NI], lm[2], la[2];
     auto read_frags = [&](int stage, int kt, int kc, f32x4 (&a)[MI], f32x4 (&b)[NI], f32x4& m, f32x4& ad) {
         const float* st = smem + stage * STAGE;
-        const int c = kc * 2 + fh;
+        const int c = (kg * NCH + kc) * 2 + fh;
 #pragma unroll
         for (int i = 0; i < MI; ++i) a[i] = *reinterpret_cast<const f32x4*>(st + a_off[i] + ((c ^ a_sw[i]) << 2));
 #pragma unroll
@@ -325,6 +331,8 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
+        // all of the tile's DMAs right behind the barrier: spreading them between the MFMA groups of the k-chunks was
+        // measured 7 % slower (fc1 86 -> 93.6 us, fc2 85 -> 91.4 us)
         issue_tile(kt + NS - 1, stage_new);   // refills the stage tile kt-1 lived in
 #pragma unroll
         for (int kc = 0; kc < NCH; ++kc) {
@@ -340,12 +348,13 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
                                                                             __builtin_bit_cast(bf16x8, bf[kc & 1][j]), acc[i][j], 0, 0, 0);
             } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                for (int e = 0; e < 4; ++e) {
 #pragma unroll
                     for (int i = 0; i < MI; ++i)
 #pragma unroll
                         for (int j = 0; j < NI; ++j)
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kc & 1][i][e], bf[kc & 1][j][e], acc[i][j], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -361,7 +370,7 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     __syncthreads();   // every wave is done reading fragments, every DMA has landed
     EpiParams e = p.epi;
     if (e.partial != nullptr) e.partial += (int64_t)split * p.M * e.ld_partial;
-    epilogue_dispatch<BM, BN, MI, NI, DNT, false>(acc, smem, e, m0, n0, wm, wn, lane, tid);
+    epilogue_dispatch<BM, BN, MI, NI, DNT, false, KG>(acc, smem, e, m0, n0, wm, wn, lane, tid, kg);
     STAMP(3);
     RSTAMP(5);
 }
@@ -377,7 +386,7 @@ static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
     return VITA_OK;
 }
 
-template <int BM, int BN, int BK, int NS, int OCC = 2>
+template <int BM, int BN, int BK, int NS, int OCC = 2, int KG = 1>
 static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     GemmParamsDma p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
@@ -385,8 +394,8 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     const bool ln = p.pro != VITA_PRO_NONE;
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0)) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(DNT);
-    if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC>), grid, block, lds, stream, p);
+    if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC, false, KG>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC, false, KG>), grid, block, lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
@@ -431,7 +440,8 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
 #else   // 5: 256x128 tiles when they still give every CU a tile (6 DMA issues per 64 MFMAs per wave instead of 4 per 32)
     if ((long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= 256 && sk == nullptr) return launch_dma<256, 128, 32, 3>(p, stream);
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
-    return launch_dma<64, 128, 64, 3>(p, stream);
+    // 64-row tile: 4 k-groups of 2 waves, a wave owns 64x64 outputs over a quarter of each k-tile (fc2 88.9 -> 84 us; 2 groups: 85 us)
+    return launch_dma<64, 128, 64, 3, 2, 4>(p, stream);
 #endif
 }
 
