@@ -36,6 +36,10 @@ int main(int argc, char** argv) {
     a.X = x; a.ldx = ldx; a.W = w; a.ldw = ldw; a.bias = b; a.Y = y; a.ldy = N; a.M = M; a.N = N; a.K = K; a.act = act;
     if (ln) { a.pro = VITA_PRO_LN_MOD; a.ln_eps = 1e-6f; a.pro_mul = pm; a.pro_add = pa; }
     if (gated) { a.gate = g; a.resid = y; a.ld_resid = N; }
+    if (getenv("SPLITK") && atoi(getenv("SPLITK"))) {   // hand the library its split-K scratch, as the orchestrators do
+        void* ws; CK(hipMalloc(&ws, vita_splitk_workspace_bytes()));
+        a.splitk_ws = ws; a.splitk_ws_bytes = vita_splitk_workspace_bytes();
+    }
     for (int i = 0; i < 5; ++i) if (vita_linear_f32(&a, 0) != 0) { printf("err: %s\n", vita_last_error()); return 1; }
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -46,6 +46,7 @@ struct GemmParamsDma {
     float* preact; int64_t ld_preact;
     int tiles_m, tiles_n;
     int sk_splits, sk_k;   // split-K: number of splits, k elements per split
+    int xcd_nbr, xcd_nbc;  // the 8 XCDs as an nbr x nbc grid of tile blocks (0: linear ranges of tile ids)
     EpiParams epi;
 };
 
@@ -142,7 +143,15 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
     }
-    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    if (p.xcd_nbr > 0) {
+        // workgroup ids go round-robin over the XCDs: XCD x = id & 7 owns block (x / nbc, x % nbc) of the tile grid, so the
+        // rows of X and W its L2 has to fetch are the block's, not a full strip's (fc1: 42 -> 33.5 MB fetched per launch)
+        const int x = (int)(blockIdx.x - split * nwg) & 7, l = (int)(blockIdx.x - split * nwg) >> 3;
+        const int br = p.tiles_m / p.xcd_nbr, bc = p.tiles_n / p.xcd_nbc;
+        tile_m = (x / p.xcd_nbc) * br + l / bc;
+        tile_n = (x % p.xcd_nbc) * bc + l % bc;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int kbase = split * p.sk_k;                                   // this workgroup reduces k in [kbase, K)
     const int K = p.sk_splits > 1 ? min(p.K, kbase + p.sk_k) : p.K;
@@ -328,12 +337,19 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
             // this wave's share of tile kt+1 has landed ...
             wait_vmcnt<(NS - 3) * DPT>();
             // ... and after the barrier everyone's has, and everyone is done reading tile kt-1
+#ifndef VITA_LAB_NOBAR     // timing-only lab builds: results are wrong without the barrier / the refills
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
         }
         // all of the tile's DMAs right behind the barrier: spreading them between the MFMA groups of the k-chunks was
-        // measured 7 % slower (fc1 86 -> 93.6 us, fc2 85 -> 91.4 us)
+        // measured 7 % slower (fc1 86 -> 93.6 us, fc2 85 -> 91.4 us); letting only one wave per SIMD issue them, or BK=32
+        // with 5-6 stages, changed nothing.  Lab decomposition (timing only): without the barrier the kernel takes the
+        // same time; without the refills fc1 73.8 us / fc2 68.2 us at 2.22 GHz instead of 87.5 / 85.0 us at 2.03 GHz, i.e.
+        // the operand traffic costs both stall cycles (fc1 +4.6 %, fc2 +12.5 % over the MFMA-only loop) and ~9 % of clock
+#ifndef VITA_LAB_NODMA
         issue_tile(kt + NS - 1, stage_new);   // refills the stage tile kt-1 lived in
+#endif
 #pragma unroll
         for (int kc = 0; kc < NCH; ++kc) {
             if (kc + 1 < NCH) read_frags(stage, kt, kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1], lm[(kc + 1) & 1], la[(kc + 1) & 1]);
@@ -391,6 +407,20 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     GemmParamsDma p = p0;
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
+    // XCD grid: minimise the operand bytes the eight L2s fetch, M * nbc + N * nbr, over the factorizations of 8 that divide
+    // the tile grid evenly (nbr = 8, nbc = 1 is what linear id ranges give)
+    {
+        long best = -1;
+        for (int nbr = 1; nbr <= 8; nbr *= 2) {
+            const int nbc = 8 / nbr;
+            if (p.tiles_m % nbr != 0 || p.tiles_n % nbc != 0) continue;
+            const long cost = (long)p.M * nbc + (long)p.N * nbr;
+            if (best < 0 || cost < best) { best = cost; p.xcd_nbr = nbr; p.xcd_nbc = nbc; }
+        }
+#ifdef VITA_XCD_LINEAR
+        p.xcd_nbr = 0;
+#endif
+    }
     const bool ln = p.pro != VITA_PRO_NONE;
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0)) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(DNT);
