@@ -58,13 +58,15 @@ int main(int argc, char** argv) {
         std::vector<unsigned long long> st(tiles * 8);
         CK(hipDeviceSynchronize());
         vita_lab_read_stamps(st.data(), tiles * 8);
-        double pro = 0, loop = 0, epi = 0, clk = 0; unsigned long long t0 = ~0ull, t3 = 0, r0 = ~0ull, r1 = 0;
+        double pro = 0, loop = 0, epi = 0, clk = 0, e_wr = 0, e_bar = 0, e_row = 0; unsigned long long t0 = ~0ull, t3 = 0, r0 = ~0ull, r1 = 0;
         for (int i = 0; i < tiles; ++i) {
+            e_wr += st[i * 8 + 6] - st[i * 8 + 2]; e_bar += st[i * 8 + 7] - st[i * 8 + 6]; e_row += st[i * 8 + 3] - st[i * 8 + 7];
             pro += st[i * 8 + 1] - st[i * 8]; loop += st[i * 8 + 2] - st[i * 8 + 1]; epi += st[i * 8 + 3] - st[i * 8 + 2];
             if (st[i * 8] < t0) t0 = st[i * 8]; if (st[i * 8 + 3] > t3) t3 = st[i * 8 + 3];
             clk += (double)(st[i * 8 + 3] - st[i * 8]) / (double)(st[i * 8 + 5] - st[i * 8 + 4]) * 0.1;   // GHz
             if (st[i * 8 + 4] < r0) r0 = st[i * 8 + 4]; if (st[i * 8 + 5] > r1) r1 = st[i * 8 + 5];
         }
+        printf("epilogue split: drain+barrier+acc->LDS %.0f | barrier %.0f | row phase %.0f\n", e_wr / tiles, e_bar / tiles, e_row / tiles);
         printf("stamps (shader cycles) tiles=%d prologue=%.0f loop=%.0f epilogue=%.0f | in-kernel clock %.3f GHz | last launch first-WG-start..last-WG-end %.2f us\n",
                tiles, pro / tiles, loop / tiles, epi / tiles, clk / tiles, (r1 - r0) * 0.01);
     }

@@ -14,6 +14,10 @@
 
 #include "vita_common.h"
 
+#ifndef VITA_EPI_STAMP
+#define VITA_EPI_STAMP(i)
+#endif
+
 namespace vita {
 
 struct EpiParams {
@@ -101,7 +105,9 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                 const int col = wn * TN + j * 32 + (lane & 31);
                 obuf[kg * (BM * S) + row * S + col] = acc[i][j][r];
             }
+    VITA_EPI_STAMP(6);
     __syncthreads();
+    VITA_EPI_STAMP(7);
     auto tile_row4 = [&](int lr, int lc) -> f32x4 {
         f32x4 a = *reinterpret_cast<const f32x4*>(obuf + lr * S + lc);
 #pragma unroll
@@ -126,6 +132,50 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
             *reinterpret_cast<f32x4*>(e.partial + (int64_t)row * e.ld_partial + col) = tile_row4(lr, lc);
         }
         return;
+    }
+    // Interior tiles with 16-byte-aligned operands (every tile of the sampler's GEMMs): a thread keeps its column for all
+    // ITERS rows, so the bias / gate vectors are loaded once and nothing is bounds-checked.
+    if constexpr (NT_ % C4 == 0) {
+        if (e.vec && m0 + BM <= e.M && n0 + BN <= e.N) {
+            constexpr int RSTEP = NT_ / C4;
+            const int lc = (tid % C4) * 4, lr0 = tid / C4;
+            const int col = n0 + lc;
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            f32x4 gv = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
+            if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
+            if (gate_vec) gv = *reinterpret_cast<const f32x4*>(e.gate + col);
+#pragma unroll
+            for (int it = 0; it < ITERS; ++it) {
+                const int lr = lr0 + it * RSTEP;
+                const int64_t row = m0 + lr;
+                const f32x4 a = tile_row4(lr, lc);
+                f32x4 zin = {0.f, 0.f, 0.f, 0.f}, rs = zin, g = gv, pre, out;
+                if constexpr (BWD) {
+                    if (pf) zin = pre_z[PREFETCH ? it : 0];
+                    else zin = *reinterpret_cast<const f32x4*>(e.act_grad_z + row * e.ld_act_grad_z + col);
+                }
+                if (gate_mat) g = *reinterpret_cast<const f32x4*>(e.gate + row * e.ld_gate + col);
+                if (has_resid) {
+                    if (pf) rs = pre_r[PREFETCH ? it : 0];
+                    else rs = *reinterpret_cast<const f32x4*>(e.resid + row * e.ld_resid + col);
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    float p_ = 0.f;
+                    out[k] = epi_elem<ACT, BWD>(a[k], b[k], zin[k], g[k], has_gate, rs[k], has_resid, e.preact ? &p_ : nullptr);
+                    pre[k] = p_;
+                }
+                if (e.preact) *reinterpret_cast<f32x4*>(e.preact + row * e.ld_preact + col) = pre;
+                if (e.Y) *reinterpret_cast<f32x4*>(e.Y + row * e.ldy + col) = out;
+                if (e.ybf) {
+                    u16x4 hb;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(out[k]);
+                    *reinterpret_cast<u16x4*>(e.ybf + row * e.ld_ybf + col) = hb;
+                }
+            }
+            return;
+        }
     }
 #pragma unroll
     for (int it = 0; it < ITERS; ++it) {

@@ -24,6 +24,34 @@
 //                 that hides under the 64-cycle fp32 MFMAs.
 #include <type_traits>
 
+#include "vita_common.h"
+
+namespace vita {
+#ifdef VITA_STAMP
+// Diagnostic build only (tools/lab_variant.sh): per-workgroup s_memtime stamps, read back by vita_lab_read_stamps.
+__device__ unsigned long long g_stamps[4096 * 8];
+#define STAMP(i)                                                                                  \
+    do {                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+        unsigned long long t__;                                                                   \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t__;          \
+        __builtin_amdgcn_sched_barrier(0);                                                        \
+    } while (0)
+#define RSTAMP(i)                                                                                 \
+    do {                                                                                          \
+        unsigned long long t__;                                                                   \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");           \
+        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t__;          \
+    } while (0)
+#else
+#define STAMP(i)
+#define RSTAMP(i)
+#endif
+
+}  // namespace vita
+#define VITA_EPI_STAMP(i) STAMP(i)
+
 #include "vita_gemm_epilogue.h"
 
 namespace vita {
@@ -53,28 +81,6 @@ struct GemmParamsDma {
 constexpr int DNT = 512;
 
 __device__ __attribute__((aligned(16))) float g_zero_chunk[4] = {0.f, 0.f, 0.f, 0.f};
-
-#ifdef VITA_STAMP
-// Diagnostic build only (tools/lab_variant.sh): per-workgroup s_memtime stamps, read back by vita_lab_read_stamps.
-__device__ unsigned long long g_stamps[4096 * 8];
-#define STAMP(i)                                                                                  \
-    do {                                                                                          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-        unsigned long long t__;                                                                   \
-        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");               \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t__;          \
-        __builtin_amdgcn_sched_barrier(0);                                                        \
-    } while (0)
-#define RSTAMP(i)                                                                                 \
-    do {                                                                                          \
-        unsigned long long t__;                                                                   \
-        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t__)::"memory");           \
-        if (threadIdx.x == 0 && blockIdx.x < 4096) g_stamps[blockIdx.x * 8 + (i)] = t__;          \
-    } while (0)
-#else
-#define STAMP(i)
-#define RSTAMP(i)
-#endif
 
 __device__ __forceinline__ void dma16(const float* g, float* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
@@ -348,7 +354,8 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
         // same time; without the refills fc1 73.8 us / fc2 68.2 us at 2.22 GHz instead of 87.5 / 85.0 us at 2.03 GHz, i.e.
         // the operand traffic costs both stall cycles (fc1 +4.6 %, fc2 +12.5 % over the MFMA-only loop) and ~9 % of clock
 #ifndef VITA_LAB_NODMA
-        issue_tile(kt + NS - 1, stage_new);   // refills the stage tile kt-1 lived in
+        issue_tile(kt + NS - 1, stage_new);   // refills the stage tile kt-1 lived in (past the last tile: dummy reads of a
+                                              // zero chunk; branching around them costs more than they do: fc2 loop +4 %)
 #endif
 #pragma unroll
         for (int kc = 0; kc < NCH; ++kc) {
