@@ -276,7 +276,10 @@ def main():
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": kernels[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic,
-                         "flops_per_launch": 2.0 * B * fw.FF * fw.H},
+                         "flops_per_launch": 2.0 * B * fw.FF * fw.H,
+                         "avg_launch_us": kernels[dom]["avg_us"],
+                         "timing": "HIP events around 20 back-to-back launches on the launch stream: includes the gap between "
+                                   "dependent kernels; rocprofv3's per-kernel duration (profiles/) excludes it, see DESIGN.md section 4"},
             "kernels": kernels,
             "train": train,
             "bf16_variant": bf16,
