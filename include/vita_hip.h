@@ -385,6 +385,39 @@ int vita_gaussian_kl_fwd_f32(const float* mean, int64_t ld_mean, const float* lo
 int vita_gaussian_kl_bwd_f32(const float* mean, int64_t ld_mean, const float* logvar, int64_t ld_logvar, int32_t B, int32_t C, const float* gout,
                              float* grad_mean, int64_t ld_gm, float* grad_logvar, int64_t ld_gv, vita_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Alternate matchers, INFERENCE only.  Their training losses are not built.
+ * --------------------------------------------------------------------------------------- */
+/* ConsistencyFlowMatcher.sample (flow/consistency_flow_matcher.py:72-106) over SimpleFlowNet: num_steps steps at
+ * t_i = i/K*(1-eps)+eps.  sigma_var == 0: z <- z + v*dt (:98).  sigma_var > 0: the update of :93-96 with
+ * sigma_t = (1-t_i)*sigma_var and the caller's standard-normal `noise` (num_steps, B, D) in place of torch.randn_like.
+ *   x0 (B,D) -> x_out (B,D); x_out may alias x0. */
+size_t vita_consistency_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps);
+int vita_consistency_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
+                                int32_t num_steps, float eps, float sigma_var, float noise_scale, const float* noise, void* workspace,
+                                size_t workspace_bytes, vita_stream_t stream);
+
+typedef struct vita_meanflow_weights { /* SimpleMeanFlowNet, policies/vita/simple_mean_flow_net.py:5-61; checkpoint layout */
+    int32_t D, H, FF, L;               /* input/output dim, hidden_dim, int(hidden_dim*mlp_ratio), num_layers */
+    const float *t1_w, *t1_b, *t2_w, *t2_b;   /* t_embed.0 (H,1), t_embed.2 (H,H) */
+    const float *h1_w, *h1_b, *h2_w, *h2_b;   /* h_embed.0, h_embed.2 */
+    const float *in_w, *in_b;                 /* input_layer (H,D) */
+    const float* fc1_w[VITA_MAX_LAYERS]; const float* fc1_b[VITA_MAX_LAYERS];   /* hidden_layers.{l}.0 (FF,H) */
+    const float* fc2_w[VITA_MAX_LAYERS]; const float* fc2_b[VITA_MAX_LAYERS];   /* hidden_layers.{l}.3 (H,FF) */
+    const float *u_w, *u_b;                   /* u_output_layer (D,H) */
+    const float *v_w, *v_b;                   /* v_output_layer (D,H); may be NULL when v is not requested */
+} vita_meanflow_weights;
+
+/* SimpleMeanFlowNet.forward(x, timestep, h) (:63-81) with per-row t and h: u (B,D) and optionally v (B,D).
+ * (internal_features, used only by the dispersive training loss, are not returned.) */
+size_t vita_meanflow_forward_workspace_bytes(const vita_meanflow_weights* w, int32_t B);
+int vita_meanflow_forward_f32(const vita_meanflow_weights* w, const float* x, int64_t ldx, const float* t, const float* h, float* u, int64_t ldu,
+                              float* v, int64_t ldv, int32_t B, void* workspace, size_t workspace_bytes, vita_stream_t stream);
+/* MeanFlowMatcher.sample (flow/mean_flow_matcher.py:201-233): for step k: t = 1 - k/K, h = 1/K, x <- x - h * u(x, t, h). */
+size_t vita_meanflow_sample_workspace_bytes(const vita_meanflow_weights* w, int32_t B, int32_t num_steps);
+int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
+                             int32_t num_steps, void* workspace, size_t workspace_bytes, vita_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -261,6 +261,89 @@ def gaussian_kl(mean: Tensor, logvar: Tensor) -> Tensor:
 
 
 # ----------------------------------------------------------------------------------------
+# alternate matchers, inference side  
+# ----------------------------------------------------------------------------------------
+def consistency_sample(sd: SD, x0: Tensor, num_steps: int, eps: float = 1e-2, sigma_var: float = 1.0,
+                       noise_scale: float = 1.0, noise: Tensor | None = None, prefix: str = "flow_net.") -> Tensor:
+    """ConsistencyFlowMatcher.sample, consistency_flow_matcher.py:72-106 with `start` given.  `noise[i]`
+    stands for the torch.randn_like draw of step i (:96)."""
+    z = x0.detach().clone()
+    dt = 1.0 / num_steps
+    for i in range(num_steps):
+        num_t = i / num_steps * (1 - eps) + eps
+        t = torch.ones(z.shape[0], dtype=z.dtype) * num_t
+        vt = flow_net_forward(sd, z, t, prefix)
+        sigma_t = (1.0 - num_t) * sigma_var
+        if sigma_t > 0:
+            pred_sigma = vt + (sigma_t ** 2) / (2 * (noise_scale ** 2) * ((1 - num_t) ** 2)) * \
+                (0.5 * num_t * (1 - num_t) * vt - 0.5 * (2 - num_t) * z)
+            z = z + pred_sigma * dt + sigma_t * math.sqrt(dt) * noise[i]
+        else:
+            z = z + vt * dt
+    return z
+
+
+def mean_flow_num_layers(sd: SD, prefix: str = "flow_net.") -> int:
+    n = 0
+    while f"{prefix}hidden_layers.{n}.0.weight" in sd:
+        n += 1
+    return n
+
+
+def mean_flow_net_forward(sd: SD, x: Tensor, timestep: Tensor, h: Tensor, prefix: str = "flow_net."):
+    """SimpleMeanFlowNet.forward, simple_mean_flow_net.py:63-81 (dropout 0) -> (u, v, internal_features)."""
+    def lin(name, y):
+        return F.linear(y, sd[prefix + name + ".weight"], sd[prefix + name + ".bias"])
+    t_emb = lin("t_embed.2", F.silu(lin("t_embed.0", timestep.unsqueeze(-1))))
+    h_emb = lin("h_embed.2", F.silu(lin("h_embed.0", h.unsqueeze(-1))))
+    time_cond = t_emb + h_emb
+    x = lin("input_layer", x)
+    feats = []
+    for l in range(mean_flow_num_layers(sd, prefix)):
+        x_cond = x + time_cond
+        x = lin(f"hidden_layers.{l}.3", F.silu(lin(f"hidden_layers.{l}.0", x_cond))) + x
+        feats.append(x)
+    return lin("u_output_layer", x), lin("v_output_layer", x), feats
+
+
+def mean_flow_sample(sd: SD, start: Tensor, num_steps: int = 1, prefix: str = "flow_net.") -> Tensor:
+    """MeanFlowMatcher.sample, mean_flow_matcher.py:201-233."""
+    x = start
+    B = x.shape[0]
+    for step in range(num_steps):
+        t_scalar = 1.0 - step / num_steps
+        r_scalar = 1.0 - (step + 1) / num_steps
+        t = torch.full((B,), t_scalar, dtype=x.dtype)
+        h = torch.full((B,), t_scalar - r_scalar, dtype=x.dtype)
+        u, _, _ = mean_flow_net_forward(sd, x, t, h, prefix)
+        x = x - h.view(-1, 1) * u
+    return x
+
+
+def make_meanflow_state_dict(latent_dim: int = 512, hidden_dim: int = 512, num_layers: int = 4, mlp_ratio: float = 4.0,
+                             seed: int = 0, dtype=torch.float32, prefix: str = "flow_net.") -> SD:
+    """Seeded weights with SimpleMeanFlowNet's keys; the output layers are NOT zero (the reference zero-initialises
+    them, which would make every parity check trivial)."""
+    g = torch.Generator().manual_seed(seed)
+    sd: SD = {}
+
+    def lin(name, out_f, in_f, bias_std=0.05):
+        bound = math.sqrt(6.0 / (in_f + out_f))
+        sd[prefix + name + ".weight"] = ((torch.rand(out_f, in_f, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+        sd[prefix + name + ".bias"] = (torch.randn(out_f, generator=g, dtype=torch.float64) * bias_std).to(dtype)
+    ff = int(hidden_dim * mlp_ratio)
+    lin("t_embed.0", hidden_dim, 1); lin("t_embed.2", hidden_dim, hidden_dim)
+    lin("h_embed.0", hidden_dim, 1); lin("h_embed.2", hidden_dim, hidden_dim)
+    lin("input_layer", hidden_dim, latent_dim)
+    for l in range(num_layers):
+        lin(f"hidden_layers.{l}.0", ff, hidden_dim)
+        lin(f"hidden_layers.{l}.3", hidden_dim, ff)
+    lin("u_output_layer", latent_dim, hidden_dim)
+    lin("v_output_layer", latent_dim, hidden_dim)
+    return sd
+
+
+# ----------------------------------------------------------------------------------------
 # policy-level entry points  (flare/policies/vita/vita_policy.py)
 # ----------------------------------------------------------------------------------------
 def generate_actions(sd: SD, obs_features: Tensor, num_steps: int, pred_horizon: int,

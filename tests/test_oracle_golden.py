@@ -32,6 +32,11 @@ def misc(golden_dir):
 
 
 @pytest.fixture(scope="module")
+def alt(golden_dir):
+    return load(os.path.join(golden_dir, "alt.safetensors"))
+
+
+@pytest.fixture(scope="module")
 def full(golden_dir):
     return load(os.path.join(golden_dir, "full.safetensors"))
 
@@ -131,3 +136,18 @@ def test_fp32_oracle_close_to_fp64_truth():
     a64 = O.generate_actions(O.cast_sd(sd, torch.float64), obs.double(), 6, 16, 21)
     err = (a32.double() - a64).abs().max().item() / a64.abs().max().item()
     assert err < 1e-5, err
+
+
+def test_alternate_matchers_inference(alt):
+    """SimpleMeanFlowNet.forward, MeanFlowMatcher.sample and ConsistencyFlowMatcher.sample (both branches) against the
+    reference's own outputs (tools/gen_golden_alt.py)."""
+    sd = {k[len("mf/sd/"):]: v for k, v in alt.items() if k.startswith("mf/sd/")}
+    u, v, _ = O.mean_flow_net_forward(sd, alt["mf/x"], alt["mf/t"], alt["mf/h"])
+    close(u, alt["mf/u"])
+    close(v, alt["mf/v"])
+    for K in (1, 2, 5):
+        close(O.mean_flow_sample(sd, alt["mf/x"], K), alt[f"mf/sample/K{K}"])
+    sd = {k[len("cfm/sd/"):]: v for k, v in alt.items() if k.startswith("cfm/sd/")}
+    for K in (1, 4):
+        close(O.consistency_sample(sd, alt["cfm/x0"], K, sigma_var=0.0), alt[f"cfm/det/K{K}"])
+        close(O.consistency_sample(sd, alt["cfm/x0"], K, noise=alt[f"cfm/sde/noise{K}"]), alt[f"cfm/sde/K{K}"])

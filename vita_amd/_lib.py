@@ -55,6 +55,18 @@ class FlowNetWeights(C.Structure):
     ]
 
 
+class MeanFlowWeights(C.Structure):
+    _fields_ = [
+        ("D", C.c_int32), ("H", C.c_int32), ("FF", C.c_int32), ("L", C.c_int32),
+        ("t1_w", c_fp), ("t1_b", c_fp), ("t2_w", c_fp), ("t2_b", c_fp),
+        ("h1_w", c_fp), ("h1_b", c_fp), ("h2_w", c_fp), ("h2_b", c_fp),
+        ("in_w", c_fp), ("in_b", c_fp),
+        ("fc1_w", _PA), ("fc1_b", _PA),
+        ("fc2_w", _PA), ("fc2_b", _PA),
+        ("u_w", c_fp), ("u_b", c_fp), ("v_w", c_fp), ("v_b", c_fp),
+    ]
+
+
 class DecoderWeights(C.Structure):
     _fields_ = [
         ("D", C.c_int32), ("HD", C.c_int32), ("NL", C.c_int32), ("OUT", C.c_int32),
@@ -166,6 +178,15 @@ SIGNATURES = {
     "vita_gaussian_kl_fwd_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, c_fp]),
     "vita_gaussian_kl_bwd_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int64, c_fp, C.c_int64,
                                            c_fp]),
+    "vita_consistency_sample_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.c_int32, C.c_int32]),
+    "vita_consistency_sample_f32": (C.c_int, [C.POINTER(FlowNetWeights), c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float,
+                                              C.c_float, C.c_float, c_fp, c_fp, C.c_size_t, c_fp]),
+    "vita_meanflow_forward_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowWeights), C.c_int32]),
+    "vita_meanflow_forward_f32": (C.c_int, [C.POINTER(MeanFlowWeights), c_fp, C.c_int64, c_fp, c_fp, c_fp, C.c_int64, c_fp, C.c_int64,
+                                            C.c_int32, c_fp, C.c_size_t, c_fp]),
+    "vita_meanflow_sample_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowWeights), C.c_int32, C.c_int32]),
+    "vita_meanflow_sample_f32": (C.c_int, [C.POINTER(MeanFlowWeights), c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp,
+                                           C.c_size_t, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

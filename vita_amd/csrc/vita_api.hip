@@ -133,6 +133,37 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
     return VITA_OK;
 }
 
+// ConsistencyFlowMatcher.sample (consistency_flow_matcher.py:72-106) over the same velocity net: step times
+// t_i = i/K*(1-eps)+eps; with sigma_t = (1-t)*sigma_var > 0 the update is the SDE-flavoured one of :93-96 with the caller's
+// noise, else the Euler update of :98 (fused into out_proj's epilogue like ode_sample).
+static int consistency_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
+                              float eps, float sigma_var, float noise_scale, const float* noise, void* ws, hipStream_t s) {
+    const int D = w->D, H = w->H, L = w->L;
+    FlowWs f = carve_flow(ws, w, B, K, true);
+    SplitkScope sk(f.sk, kSplitkBytes);
+    VITA_TRY(launch_step_times_affine(f.ts, K, 1.0 - (double)eps, (double)eps, s));
+    VITA_TRY(time_path(w, f, K, s));
+    const double dt = 1.0 / (double)K;
+    const float* src = x0;
+    int64_t lds = ldx0;
+    for (int k = 0; k < K; ++k) {
+        const float* mod = f.mod + (size_t)k * L * 3 * H;
+        const double t = (double)k / (double)K * (1.0 - (double)eps) + (double)eps;
+        const double sigma_t = (1.0 - t) * (double)sigma_var;
+        if (sigma_t > 0.0) {
+            VITA_TRY(flow_eval(w, f, src, lds, mod, 0, f.x, D, nullptr, 0, 0.f, B, s));
+            const double coef = (sigma_t * sigma_t) / (2.0 * ((double)noise_scale * (double)noise_scale) * ((1.0 - t) * (1.0 - t)));
+            VITA_TRY(launch_sde_update(src, lds, f.x, noise + (size_t)k * B * D, x_out, ldo, B, D, (float)(0.5 * t * (1.0 - t)),
+                                       (float)(0.5 * (2.0 - t)), (float)coef, (float)dt, (float)(sigma_t * sqrt(dt)), s));
+        } else {
+            VITA_TRY(flow_eval(w, f, src, lds, mod, 0, x_out, ldo, src, lds, (float)dt, B, s));
+        }
+        src = x_out;
+        lds = ldo;
+    }
+    return VITA_OK;
+}
+
 struct DecWs { float *sk, *a, *b; size_t bytes; };
 static DecWs carve_dec(void* ws, const vita_decoder_weights* w, int B) {
     Carver c(ws);
@@ -215,6 +246,26 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
     VITA_REQUIRE(x0 && x_out && ldx0 >= w->D && ldo >= w->D, "vita_ode_sample_f32: bad x0/x_out");
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_ode_sample_workspace_bytes(w, B, num_steps), "vita_ode_sample_f32"));
     return ode_sample(w, x0, ldx0, x_out, ldo, B, num_steps, traj, workspace, (hipStream_t)stream);
+}
+
+size_t vita_consistency_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {
+    if (!w || B <= 0 || num_steps <= 0) return 0;
+    return carve_flow(nullptr, w, B, num_steps, true).bytes;
+}
+
+int vita_consistency_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
+                                int32_t num_steps, float eps, float sigma_var, float noise_scale, const float* noise, void* workspace,
+                                size_t workspace_bytes, vita_stream_t stream) {
+    const char* who = "vita_consistency_sample_f32";
+    VITA_TRY(check_flow_weights(w, who));
+    VITA_REQUIRE(num_steps >= 1, "%s: num_steps must be >= 1 (got %d)", who, num_steps);
+    VITA_REQUIRE(eps >= 0.f && eps < 1.f && sigma_var >= 0.f, "%s: eps must be in [0,1) and sigma_var >= 0", who);
+    VITA_REQUIRE(sigma_var == 0.f || (noise != nullptr && noise_scale > 0.f), "%s: sigma_var > 0 needs the noise tensor and noise_scale > 0", who);
+    VITA_REQUIRE(B >= 0, "%s: B < 0", who);
+    if (B == 0) return VITA_OK;
+    VITA_REQUIRE(x0 && x_out && ldx0 >= w->D && ldo >= w->D, "%s: bad x0/x_out", who);
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_consistency_sample_workspace_bytes(w, B, num_steps), who));
+    return consistency_sample(w, x0, ldx0, x_out, ldo, B, num_steps, eps, sigma_var, noise_scale, noise, workspace, (hipStream_t)stream);
 }
 
 size_t vita_decoder_forward_workspace_bytes(const vita_decoder_weights* w, int32_t B) {

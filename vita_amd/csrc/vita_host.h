@@ -89,6 +89,11 @@ int nce_forward(const float* a, int64_t lda, const float* b, int64_t ldb, int B,
 int nce_backward(int B, int D, float temperature, const float* gout, float* da, int64_t ld_da, int acc_a, float* db, int64_t ld_db, int acc_b,
                  void* ws, hipStream_t s);
 int launch_axpy(const float* x, float* y, int64_t n, hipStream_t s);   // y += x
+// alternate samplers (vita_meanflow.hip)
+int launch_step_times_affine(float* ts, int K, double scale, double offset, hipStream_t s);   // ts[k] = (float)(k/K*scale + offset)
+int launch_sde_update(const float* z, int64_t ldz, const float* v, const float* noise, float* out, int64_t ldo, int B, int D, float c_v,
+                      float c_z, float coef, float dt, float s_noise, hipStream_t s);
+int launch_add_rows(const float* x, int64_t ldx, const float* r, int64_t ldr, float* out, int64_t ldo, int M, int N, hipStream_t s);
 
 int check_flow_weights(const vita_flownet_weights* w, const char* who);
 int check_dec_weights(const vita_decoder_weights* w, const char* who);

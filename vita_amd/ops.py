@@ -275,6 +275,94 @@ def generate_actions(obs_w: Tensor, obs_b: Tensor, fw: FlowNetHandle, dw: Decode
 
 
 # --------------------------------------------------------------------------------------
+# alternate matchers (inference): Consistency-FM sampler, SimpleMeanFlowNet + MeanFlow sampler
+# --------------------------------------------------------------------------------------
+def consistency_sample(fw: FlowNetHandle, x0: Tensor, num_steps: int, eps: float = 1e-2, sigma_var: float = 1.0,
+                       noise_scale: float = 1.0, noise: Optional[Tensor] = None) -> Tensor:
+    """ConsistencyFlowMatcher.sample (consistency_flow_matcher.py:72-106).  `noise` (num_steps, B, D): the standard-normal
+    draws the reference takes from torch.randn_like at every step (needed when sigma_var > 0)."""
+    lib = L.load()
+    x0 = _rows(x0, "consistency_sample: x0")
+    B, D = x0.shape
+    if D != fw.D:
+        raise L.VitaHipError(f"consistency_sample: x0 has {D} columns, the flow net expects {fw.D}")
+    if sigma_var > 0:
+        if noise is None:
+            raise L.VitaHipError("consistency_sample: sigma_var > 0 needs the per-step noise (num_steps, B, D)")
+        noise = _f32(noise, "consistency_sample: noise").contiguous()
+        if tuple(noise.shape) != (num_steps, B, D):
+            raise L.VitaHipError(f"consistency_sample: noise must be {(num_steps, B, D)}, got {tuple(noise.shape)}")
+    out = torch.empty((B, D), dtype=torch.float32, device=x0.device)
+    nbytes = lib.vita_consistency_sample_workspace_bytes(C.byref(fw.w), B, num_steps)
+    ws = workspace(x0.device, nbytes)
+    L.check(lib.vita_consistency_sample_f32(C.byref(fw.w), x0.data_ptr(), _ld(x0), out.data_ptr(), D, B, num_steps, float(eps),
+                                            float(sigma_var), float(noise_scale), noise.data_ptr() if noise is not None else None,
+                                            ws.data_ptr(), ws.numel(), _stream(x0)), "vita_consistency_sample_f32")
+    return out
+
+
+class MeanFlowNetHandle:
+    """vita_meanflow_weights over a state dict with SimpleMeanFlowNet's keys (simple_mean_flow_net.py:20-47)."""
+
+    def __init__(self, sd: Mapping[str, Tensor], device, prefix: str = "flow_net."):
+        device = torch.device(device)
+        self.t = {}
+        g = lambda k: self.t.setdefault(k, _prep(sd, prefix + k, device))  # noqa: E731
+        w = L.MeanFlowWeights()
+        iw = g("input_layer.weight")
+        w.H, w.D = iw.shape
+        n = 0
+        while f"{prefix}hidden_layers.{n}.0.weight" in sd:
+            n += 1
+        if n > L.MAX_LAYERS:
+            raise L.VitaHipError(f"MeanFlowNetHandle: {n} layers > {L.MAX_LAYERS}")
+        w.L = n
+        w.FF = g("hidden_layers.0.0.weight").shape[0] if n else w.H
+        for a, b in (("t1", "t_embed.0"), ("t2", "t_embed.2"), ("h1", "h_embed.0"), ("h2", "h_embed.2"), ("in", "input_layer"),
+                     ("u", "u_output_layer"), ("v", "v_output_layer")):
+            setattr(w, a + "_w", g(b + ".weight").data_ptr())
+            setattr(w, a + "_b", g(b + ".bias").data_ptr())
+        for l in range(n):
+            w.fc1_w[l], w.fc1_b[l] = g(f"hidden_layers.{l}.0.weight").data_ptr(), g(f"hidden_layers.{l}.0.bias").data_ptr()
+            w.fc2_w[l], w.fc2_b[l] = g(f"hidden_layers.{l}.3.weight").data_ptr(), g(f"hidden_layers.{l}.3.bias").data_ptr()
+        self.w, self.D, self.H, self.FF, self.L, self.device = w, w.D, w.H, w.FF, n, device
+
+
+def meanflow_forward(mw: MeanFlowNetHandle, x: Tensor, t: Tensor, h: Tensor, need_v: bool = True):
+    """SimpleMeanFlowNet.forward(x, timestep, h) -> (u, v) (simple_mean_flow_net.py:63-81; internal_features not returned)."""
+    lib = L.load()
+    x = _rows(x, "meanflow_forward: x")
+    t = _f32(t, "meanflow_forward: t").contiguous()
+    h = _f32(h, "meanflow_forward: h").contiguous()
+    B, D = x.shape
+    if D != mw.D or tuple(t.shape) != (B,) or tuple(h.shape) != (B,):
+        raise L.VitaHipError(f"meanflow_forward: x {tuple(x.shape)} / t {tuple(t.shape)} / h {tuple(h.shape)} do not match D={mw.D}")
+    u = torch.empty((B, D), dtype=torch.float32, device=x.device)
+    v = torch.empty((B, D), dtype=torch.float32, device=x.device) if need_v else None
+    nbytes = lib.vita_meanflow_forward_workspace_bytes(C.byref(mw.w), B)
+    ws = workspace(x.device, nbytes)
+    L.check(lib.vita_meanflow_forward_f32(C.byref(mw.w), x.data_ptr(), _ld(x), t.data_ptr(), h.data_ptr(), u.data_ptr(), D,
+                                          v.data_ptr() if v is not None else None, D, B, ws.data_ptr(), ws.numel(), _stream(x)),
+            "vita_meanflow_forward_f32")
+    return u, v
+
+
+def meanflow_sample(mw: MeanFlowNetHandle, x0: Tensor, num_steps: int = 1) -> Tensor:
+    """MeanFlowMatcher.sample (mean_flow_matcher.py:201-233): x <- x - h * u(x, t, h), one C-ABI call for all steps."""
+    lib = L.load()
+    x0 = _rows(x0, "meanflow_sample: x0")
+    B, D = x0.shape
+    if D != mw.D:
+        raise L.VitaHipError(f"meanflow_sample: x0 has {D} columns, the net expects {mw.D}")
+    out = torch.empty((B, D), dtype=torch.float32, device=x0.device)
+    nbytes = lib.vita_meanflow_sample_workspace_bytes(C.byref(mw.w), B, num_steps)
+    ws = workspace(x0.device, nbytes)
+    L.check(lib.vita_meanflow_sample_f32(C.byref(mw.w), x0.data_ptr(), _ld(x0), out.data_ptr(), D, B, num_steps, ws.data_ptr(),
+                                         ws.numel(), _stream(x0)), "vita_meanflow_sample_f32")
+    return out
+
+
+# --------------------------------------------------------------------------------------
 # losses / elementwise
 # --------------------------------------------------------------------------------------
 def _loss_fwd(fn_name: str, a: Tensor, b: Tensor) -> Tensor:
