@@ -249,6 +249,44 @@ def test_freeze_flags_and_contrastive_terms_at_policy_level():
         assert same == k.startswith("action_encoder."), k
 
 
+@pytest.mark.parametrize("matcher", ["mean", "consistency"])
+def test_alternate_matchers_generate_actions(matcher):
+    """policy.flow_matcher.name = mean / consistency (vita_policy.py:53,84-97): generate_actions runs obs_encoder -> the
+    matcher's sampler -> decoder on the HIP path and matches the oracle; training raises (not built)."""
+    cfg = small_cfg(matcher=matcher)
+    if matcher == "mean":
+        cfg.policy.flow_net.name = "simple_mean_flow_net"
+        cfg.policy.flow_matcher.num_sampling_steps = 1
+    else:
+        cfg.policy.flow_matcher.pop("sigma")     # vita.yaml's torchcfm key; the Consistency matcher's constructor rejects it
+        cfg.policy.flow_matcher.merge({"num_sampling_steps": 3, "sigma_var": 0.0})
+    pol = make_policy(cfg)
+    with torch.no_grad():      # the reference zero-initialises the MeanFlow heads: give them values
+        for k, p in pol.named_parameters():
+            if "output_layer" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(3)))
+    pol = pol.to(DEV)
+    g = torch.Generator().manual_seed(8)
+    B = 9
+    batch = make_batch(cfg, B, g, with_action=False)
+    nb = pol.normalize_inputs({k: v.to(DEV) for k, v in batch.items()})
+    acts = pol.generate_actions(nb)
+    sd = hot_sd(pol)
+    feats, _ = oracle_features(pol, batch, cfg)
+    z0 = O.obs_encode(sd, feats)
+    z = O.mean_flow_sample(sd, z0, 1) if matcher == "mean" else O.consistency_sample(sd, z0, 3, sigma_var=0.0)
+    ref = O.simple_action_decode(sd, z, cfg.policy.pred_horizon, cfg.task.action_dim)
+    assert acts.shape == ref.shape and nerr(acts, ref) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        pol.compute_loss(nb)
+    if matcher == "consistency":   # default sigma_var = 1.0: stochastic sampler, finite and different from the ODE branch
+        cfg2 = small_cfg(matcher=matcher)
+        cfg2.policy.flow_matcher.pop("sigma")
+        pol2 = make_policy(cfg2).to(DEV)
+        a2 = pol2.generate_actions(nb)
+        assert torch.isfinite(a2).all()
+
+
 def test_full_size_training_step_properties_b4096():
     """hook_package dims at B = 4096 per GPU (the large-batch data-parallel regime): finite, deterministic, and the
     gradient of a batch equals the mean of the gradients of its two halves (what the all-reduce relies on)."""

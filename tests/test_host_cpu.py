@@ -112,9 +112,20 @@ def test_flow_matcher_table():
     assert get_flow_matcher("exact", sigma=0.0, num_sampling_steps=6).pairing == "exact"
     assert get_flow_matcher("conditional").num_sampling_steps == 6
     with pytest.raises(NotImplementedError):
-        get_flow_matcher("mean")
+        get_flow_matcher("target")
     with pytest.raises(NotImplementedError):
         get_flow_matcher("exact", sigma=0.1)
+    # sampler-only matchers: constructor arguments as in the reference, training refused
+    m = get_flow_matcher("mean", sigma=0.0, num_sampling_steps=1, flow_ratio=0.25)          # MeanFlow swallows **kwargs (:56)
+    assert m.inference_only and m.flow_ratio == 0.25 and not m.use_imf and get_flow_matcher("improved_mean").use_imf
+    with pytest.raises(NotImplementedError):
+        m.compute_loss(None, torch.zeros(2, 4))
+    with pytest.raises(ValueError):
+        m.sample(None, (2, 4), "cpu")                                                         # needs `start` (:205-206)
+    c = get_flow_matcher("consistency", eps=0.02)
+    assert c.inference_only and c.eps == 0.02 and c.sigma_var == 1.0 and abs(c.sigma_t(0.25) - 0.75) < 1e-12
+    with pytest.raises(TypeError):
+        get_flow_matcher("consistency", sigma=0.0)                                            # no such argument in the reference either
 
 
 def test_exact_ot_pairing_is_a_sample_from_the_optimal_permutation():

@@ -100,6 +100,92 @@ class ExactOptimalTransportConditionalFlowMatcher(TorchFlowMatcher):
     pairing = "exact"
 
 
+class _InferenceOnlyMatcher:
+    """Matchers whose sampler is built and whose training loss is not (SURVEY.md 8(a) a16 / 8(f) #4)."""
+
+    inference_only = True
+    pairing = "identity"
+
+    def draw(self, x0, x1):
+        raise NotImplementedError(f"{type(self).__name__}: the training loss of this matcher is not built")
+
+
+class MeanFlowMatcher(_InferenceOnlyMatcher):
+    """flow/mean_flow_matcher.py:42-233 — constructor arguments kept; `.sample` is ONE C-ABI call over a
+    `vita_amd.ops.MeanFlowNetHandle` (SimpleMeanFlowNet).  `.compute_loss` (JVP through the net with create_graph,
+    logit-normal (t, r) sampling, adaptive / dispersive losses, :109-199) is not built."""
+
+    def __init__(self, flow_ratio=0.5, time_dist_mu=-0.4, time_dist_sigma=1.0, adaptive_loss_gamma=0.5, norm_p=1.0, norm_eps=0.01,
+                 aux_v_loss_weight=1.0, dispersive_loss_tau=1.0, dispersive_loss_weight=0.0, cfg_scale=0.5, use_imf=False, **kwargs):
+        self.flow_ratio, self.time_dist_mu, self.time_dist_sigma = flow_ratio, time_dist_mu, time_dist_sigma
+        self.adaptive_loss_gamma, self.norm_p, self.norm_eps = adaptive_loss_gamma, norm_p, norm_eps
+        self.aux_v_loss_weight, self.dispersive_loss_tau = aux_v_loss_weight, dispersive_loss_tau
+        self.dispersive_loss_weight, self.cfg_scale, self.use_imf = dispersive_loss_weight, cfg_scale, use_imf
+        self.num_sampling_steps = 1
+
+    def compute_loss(self, model, target, start=None, **kwargs):
+        raise NotImplementedError("MeanFlow training (mean_flow_matcher.py:109-199: jvp with create_graph, adaptive and dispersive "
+                                  "losses) is not built; only MeanFlowMatcher.sample runs on the HIP path")
+
+    def sample(self, model: "ops.MeanFlowNetHandle", shape, device, num_steps=None, return_traces=False, start=None, **kwargs):
+        """mean_flow_matcher.py:201-233."""
+        if start is None:
+            raise ValueError("MeanFlowMatcher requires a 'start' (vision latent) tensor for sampling.")      # :205-206
+        if not isinstance(model, ops.MeanFlowNetHandle):
+            raise TypeError("MeanFlowMatcher.sample needs a SimpleMeanFlowNet (policy.flow_net.name: simple_mean_flow_net)")
+        if return_traces:
+            raise NotImplementedError("return_traces is not built for the MeanFlow sampler")
+        return ops.meanflow_sample(model, start, self.num_sampling_steps if num_steps is None else num_steps)
+
+
+class MeanFlowConditionalFlowMatcher(MeanFlowMatcher):
+    def __init__(self, num_sampling_steps=1, **kwargs):                     # flow_matchers.py:107-111
+        if num_sampling_steps != 1:
+            print("Warning: MeanFlow is designed for 1-NFE generation.")
+        super().__init__(**kwargs)
+        self.num_sampling_steps = num_sampling_steps
+
+
+class ImprovedMeanFlowConditionalFlowMatcher(MeanFlowMatcher):
+    def __init__(self, num_sampling_steps=1, **kwargs):                     # flow_matchers.py:119-125
+        kwargs["use_imf"] = True
+        if num_sampling_steps != 1:
+            print("Warning: Improved MeanFlow is designed for 1-NFE generation.")
+        super().__init__(**kwargs)
+        self.num_sampling_steps = num_sampling_steps
+
+
+class ConsistencyFlowMatcher(_InferenceOnlyMatcher):
+    """flow/consistency_flow_matcher.py:7-127 + flow_matchers.py:128-132.  `.sample` is ONE C-ABI call over the
+    SimpleFlowNet handle; with sigma_var > 0 (the default 1.0) the per-step standard-normal draws the reference takes from
+    torch.randn_like are drawn here in one torch.randn call (or passed as `noise=`).  `.compute_loss` cannot run on VITA's
+    2-D latents in the reference either (it indexes target.shape[2], :44) and is not built."""
+
+    def __init__(self, num_sampling_steps=1, eps=1e-2, num_segments=2, boundary=1, delta=1e-3, alpha=1e-5, noise_scale=1.0,
+                 sigma_var=1.0, ode_tol=1e-5):
+        if num_sampling_steps != 1:
+            print("Warning: ConsistencyFlow is designed for 1-NFE generation.")
+        self.eps, self.num_segments, self.boundary, self.delta, self.alpha = eps, num_segments, boundary, delta, alpha
+        self.noise_scale, self.sigma_var, self.ode_tol = noise_scale, sigma_var, ode_tol
+        self.sigma_t = lambda t: (1. - t) * sigma_var
+        self.num_sampling_steps = num_sampling_steps
+
+    def compute_loss(self, model, target, start=None, **kwargs):
+        raise NotImplementedError("Consistency-FM training is not built (and the reference's loss indexes target.shape[2], "
+                                  "consistency_flow_matcher.py:44, so it does not accept VITA's (B, D) latents)")
+
+    def sample(self, model: "ops.FlowNetHandle", shape, device, num_steps=None, return_traces=False, start=None, noise=None, **kwargs):
+        if num_steps is None:
+            num_steps = self.num_sampling_steps
+        if return_traces:
+            raise NotImplementedError("return_traces is not built for the Consistency-FM sampler")
+        z = torch.randn(shape, device=device) if start is None else start
+        if self.sigma_var > 0 and noise is None:
+            noise = torch.randn((num_steps,) + tuple(z.shape), device=z.device, dtype=torch.float32)
+        return ops.consistency_sample(model, z, num_steps, eps=self.eps, sigma_var=self.sigma_var, noise_scale=self.noise_scale,
+                                      noise=noise)
+
+
 def _not_yet(name):
     class _NotBuilt:
         def __init__(self, *a, **k):
@@ -114,9 +200,9 @@ FLOW_MATCHER_CLASSES = {                       # flow_matchers.py:137-145
     "exact": ExactOptimalTransportConditionalFlowMatcher,
     "target": _not_yet("target"),
     "schrodinger": _not_yet("schrodinger"),
-    "mean": _not_yet("mean"),
-    "improved_mean": _not_yet("improved_mean"),
-    "consistency": _not_yet("consistency"),
+    "mean": MeanFlowConditionalFlowMatcher,
+    "improved_mean": ImprovedMeanFlowConditionalFlowMatcher,
+    "consistency": ConsistencyFlowMatcher,
 }
 
 

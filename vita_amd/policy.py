@@ -25,8 +25,9 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import ops
-from .flow import get_flow_matcher
+from .flow import MeanFlowMatcher, get_flow_matcher
 
+MEAN_FLOW_NET_NAME = "simple_mean_flow_net"          # vita_policy.py:86-87
 FLOW_NET_NAMES = ("simple_flow_net", "simple")  # vita.yaml:28 ships "simple", vita_policy.py:84 accepts "simple_flow_net"
 
 
@@ -117,6 +118,27 @@ def make_flow_net(D, H, L_, mlp_ratio, time_embed_dim=256) -> nn.Module:
     _xavier(net)
     nn.init.normal_(net.time_embed[1].weight, std=0.02)
     nn.init.normal_(net.time_embed[3].weight, std=0.02)
+    return net
+
+
+def make_mean_flow_net(D, H, L_, mlp_ratio) -> nn.Module:
+    """SimpleMeanFlowNet's parameters, keys and init (simple_mean_flow_net.py:20-61: Xavier, zero biases, zero u/v heads)."""
+    net = _Holder()
+    net.t_embed = nn.Sequential(nn.Linear(1, H), nn.SiLU(), nn.Linear(H, H))
+    net.h_embed = nn.Sequential(nn.Linear(1, H), nn.SiLU(), nn.Linear(H, H))
+    net.input_layer = nn.Linear(D, H)
+    dim = int(H * mlp_ratio)
+    net.hidden_layers = nn.ModuleList([nn.Sequential(nn.Linear(H, dim), nn.SiLU(), nn.Dropout(p=0.0), nn.Linear(dim, H))
+                                       for _ in range(L_)])
+    net.u_output_layer = nn.Linear(H, D)
+    net.v_output_layer = nn.Linear(H, D)
+    for m in net.modules():
+        if isinstance(m, nn.Linear):
+            nn.init.xavier_uniform_(m.weight)
+            nn.init.constant_(m.bias, 0)
+    for head in (net.u_output_layer, net.v_output_layer):
+        nn.init.constant_(head.weight, 0)
+        nn.init.constant_(head.bias, 0)
     return net
 
 
@@ -242,11 +264,19 @@ class VitaPolicy(nn.Module):
         self.action_decoder = make_action_decoder(net.decoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
                                                   net.dec_hidden_dim, net.num_layers)
         fn = pol.flow_net
-        if fn.name not in FLOW_NET_NAMES:
+        if fn.name not in FLOW_NET_NAMES + (MEAN_FLOW_NET_NAME,):
             raise ValueError(f"Unsupported flow_net: {fn.name}")                                         # :89
         if float(fn.get("dropout", 0.0)) != 0.0:
             raise NotImplementedError("flow_net.dropout > 0 is not implemented (vita.yaml:32 uses 0.0)")
-        self.flow_net = make_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)      # :90-97
+        # alternate matchers (mean / improved_mean / consistency): sampler only, see flow.py
+        self.inference_only = bool(getattr(self.FM, "inference_only", False))
+        self.mean_flow = fn.name == MEAN_FLOW_NET_NAME
+        if self.mean_flow != isinstance(self.FM, MeanFlowMatcher):
+            raise ValueError("flow_net 'simple_mean_flow_net' goes with the 'mean' / 'improved_mean' flow matchers, and only with them")
+        if self.mean_flow:
+            self.flow_net = make_mean_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)
+        else:
+            self.flow_net = make_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)  # :90-97
         self._loss_cfg = ops.loss_config(num_steps=self.num_sampling_steps, recon=ae.recon_loss_type,
                                          decode_flow_latents=bool(pol.vita.decode_flow_latents),
                                          consistency_weight=float(pol.vita.consistency_weight),
@@ -331,14 +361,18 @@ class VitaPolicy(nn.Module):
 
     def _key(self):
         w = self.obs_encoder.weight
-        return (w.data_ptr(), w.device, self.flow_net.out_proj.bias.data_ptr())
+        last = self.flow_net.v_output_layer if self.mean_flow else self.flow_net.out_proj
+        return (w.data_ptr(), w.device, last.bias.data_ptr())
 
     def _infer_handles(self):
         c = self._cache.get("infer")
         if c is None or c[0] != self._key():
             sd = {k: p.data for k, p in self.named_parameters()}
             dev = self.obs_encoder.weight.device
-            c = (self._key(), ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), ops.PolicyHandle(sd, dev, self.pred_horizon))
+            if self.mean_flow:
+                c = (self._key(), ops.MeanFlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), None)
+            else:
+                c = (self._key(), ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), ops.PolicyHandle(sd, dev, self.pred_horizon))
             self._cache["infer"] = c
         return c[1], c[2], c[3]
 
@@ -401,6 +435,9 @@ class VitaPolicy(nn.Module):
     def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None):
         """Native training entry (no autograd): normalised batch -> losses (device float[8], _lib.LOSS_NAMES order), with
         d loss / d parameter written into the parameters' .grad buffers.  No host synchronisation."""
+        if self.inference_only:
+            raise NotImplementedError(f"training with flow matcher '{self.config.policy.flow_matcher.name}' is not built "
+                                      "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
         t, pair_i, pair_j = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions)
@@ -416,6 +453,9 @@ class VitaPolicy(nn.Module):
         """vita_policy.py:112-189.  Returns (loss, metrics) with the reference's metric keys; `loss` supports
         .backward() (drop-in for policy_trainer.py:79-82).  One device->host copy for all metrics (the reference
         does one .item() per metric)."""
+        if self.inference_only:
+            raise NotImplementedError(f"training with flow matcher '{self.config.policy.flow_matcher.name}' is not built "
+                                      "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
         t, pair_i, pair_j = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions)
@@ -448,6 +488,10 @@ class VitaPolicy(nn.Module):
         """vita_policy.py:191-208: observer features -> obs_encoder -> K Euler steps -> decoder, one C-ABI call."""
         obs_features = self.observer(batch)
         fw, dw, _ = self._infer_handles()
+        if self.inference_only:   # mean / improved_mean / consistency: obs_encoder -> FM.sample -> decoder, three C-ABI calls
+            z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
+            z = self.FM.sample(fw, shape=tuple(z0.shape), device=z0.device, start=z0, num_steps=self.num_sampling_steps)
+            return ops.decoder_forward(dw, z).view(-1, self.pred_horizon, self.action_dim)
         if self.gemm_dtype == "bf16":
             out = ops.generate_actions_bf16(self.obs_encoder.bias.data, fw, dw, self._bf16_weights(), obs_features,
                                             self.num_sampling_steps)
