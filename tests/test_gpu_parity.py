@@ -380,3 +380,25 @@ def test_layernorm_modulate(ops, dev, M, H, per_row):
 
 def test_sinusoid_golden(ops, dev, misc):
     close(ops.sinusoidal_embed(misc["misc/sin_t"].to(dev), 256), misc["misc/sin_e"], 1e-6)
+
+
+@pytest.mark.parametrize("B,K,traces", [(1024, 1, False), (1024, 6, True), (2048, 3, False)])
+def test_folded_layernorm_path_matches_the_layernorm_kernels(ops, dev, B, K, traces):
+    """At B >= 1024 (B % 256 == 0) the sampler folds the LayerNorms into the GEMM epilogues (vita_api.hip: use_ln_fold);
+    halves of 512 rows take the LayerNorm-kernel path.  Same rows, two code paths: agreement to fp32 rounding, and the
+    fp64 oracle on a row sample to the usual 1e-5."""
+    sd = O.make_state_dict(555, 7, seed=3)
+    fw = ops.FlowNetHandle(sd, dev)
+    g = torch.Generator().manual_seed(B + K)
+    x0 = torch.randn(B, 512, generator=g)
+    if traces:
+        out, traj = ops.ode_sample(fw, x0.to(dev), K, return_traces=True)
+        assert torch.equal(traj[-1], out) and torch.equal(traj[0].cpu(), x0)
+    else:
+        out = ops.ode_sample(fw, x0.to(dev), K)
+    parts = torch.cat([ops.ode_sample(fw, x0[i:i + 512].to(dev), K) for i in range(0, B, 512)])
+    close(out, parts, 2e-6, "folded vs LayerNorm-kernel path")
+    idx = torch.arange(0, B, B // 16)
+    sd64 = {k: v.double() for k, v in sd.items() if k.startswith("flow_net.")}
+    close(out[idx.to(dev)], O.euler_sample(sd64, x0[idx].double(), K), TOL, "folded path vs fp64 oracle")
+    assert torch.equal(out, ops.ode_sample(fw, x0.to(dev), K)), "folded path not deterministic"

@@ -4,6 +4,7 @@
 // workspace and enqueues launches on the caller's stream.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "vita_host.h"
 
@@ -20,8 +21,19 @@ void set_error(const char* fmt, ...) {
 
 struct FlowWs {
     float *sk, *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
+    float *stat, *c1, *c2, *c1f, *c2f;   // folded LayerNorm (sampling at large batch): row statistics and the c-tables
     size_t bytes;
 };
+
+// LayerNorm folded into the GEMM epilogues instead of 5 LayerNorm launches per Euler step.  With m = 1 + scale:
+//   fc1(LN(h) * m + shift) = rstd * (hm . W1^T - mean * c1) + c2,   hm = h * m,  c1 = W1 m,  c2 = W1 shift + b1,
+// so the producer of h (in_proj / fc2) also writes hm and per-tile row statistics, the consumer (fc1 / out_proj) finishes
+// the normalisation on its accumulators, and c1 / c2 are (K, L, FF) tables built once per solve (the modulation depends
+// only on the step).  Needs every tile interior: B % 256 == 0 and 128-multiples for H, FF, D.  VITA_NO_LN_FOLD=1 disables.
+static bool use_ln_fold(const vita_flownet_weights* w, int B) {
+    static const bool off = getenv("VITA_NO_LN_FOLD") != nullptr && atoi(getenv("VITA_NO_LN_FOLD")) != 0;
+    return !off && B >= 1024 && B % 256 == 0 && w->L >= 1 && w->H % 128 == 0 && w->H <= 2048 && w->FF % 128 == 0 && w->D % 128 == 0;
+}
 // T = number of distinct timesteps (num_steps when sampling, B for per-row t)
 static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, bool need_x) {
     Carver c(ws);
@@ -36,6 +48,14 @@ static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, 
     f.hn = c.take((size_t)B * w->H);
     f.u = c.take((size_t)B * w->FF);
     f.x = need_x ? c.take((size_t)B * w->D) : nullptr;
+    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = nullptr;
+    if (T != B && use_ln_fold(w, B)) {   // sampling only (per-row t has per-row modulation: no shared tables)
+        f.stat = c.take((size_t)(w->H / 128) * B * 2);
+        f.c1 = c.take((size_t)T * w->L * w->FF);
+        f.c2 = c.take((size_t)T * w->L * w->FF);
+        f.c1f = c.take((size_t)w->D);
+        f.c2f = c.take((size_t)w->D);
+    }
     f.bytes = c.off;
     return f;
 }
@@ -108,6 +128,37 @@ static int flow_eval(const vita_flownet_weights* w, const FlowWs& f, const float
     return VITA_OK;
 }
 
+static int fold_tables(const vita_flownet_weights* w, const FlowWs& f, int T, hipStream_t s) {
+    return launch_ln_fold_tables_all(w, f.mod, T, f.c1, f.c2, f.c1f, f.c2f, s);
+}
+
+// flow_eval with the LayerNorms folded (sampling: one modulation row for the batch); k = step index into the c-tables
+static int flow_eval_folded(const vita_flownet_weights* w, const FlowWs& f, const float* x, int64_t ldx, const float* mod, int k, float* Y,
+                            int64_t ldy, const float* resid, int64_t ld_resid, float dt, int B, hipStream_t s) {
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, nseg = H / 128;
+    auto producer = [&](vita_linear_args a, const float* next_mul, int add_one) -> int {
+        EpiFold e;
+        e.aux_out = f.hn; e.ld_aux = H; e.aux_mul = next_mul; e.aux_add_one = add_one; e.stat_out = f.stat;
+        return gemm_f32_fold(a, e, s);
+    };
+    VITA_TRY(producer(lin(x, ldx, w->in_w, D, w->in_b, f.h, H, B, H, D, VITA_ACT_NONE), mod + H, 1));            // h, h*(1+scale_0), stats
+    for (int l = 0; l < L; ++l) {
+        const float* gamma = mod + (size_t)l * 3 * H;
+        EpiFold c;
+        c.ln_stats = f.stat; c.ln_c1 = f.c1 + ((size_t)k * L + l) * FF; c.ln_nseg = nseg; c.ln_fold_eps = 1e-6f;
+        VITA_TRY(gemm_f32_fold(lin(f.hn, H, w->fc1_w[l], H, f.c2 + ((size_t)k * L + l) * FF, f.u, FF, B, FF, H, VITA_ACT_GELU_TANH), c, s));
+        vita_linear_args b = lin(f.u, FF, w->fc2_w[l], FF, w->fc2_b[l], f.h, H, B, H, FF, VITA_ACT_NONE);
+        b.gate = gamma; b.ld_gate = 0; b.resid = f.h; b.ld_resid = H;
+        if (l + 1 < L) VITA_TRY(producer(b, mod + (size_t)(l + 1) * 3 * H + H, 1));
+        else VITA_TRY(producer(b, w->norm_w, 0));
+    }
+    vita_linear_args o = lin(f.hn, H, w->out_w, H, f.c2f, Y, ldy, B, D, H, VITA_ACT_NONE);
+    if (resid) { o.use_gate_scalar = 1; o.gate_scalar = dt; o.resid = resid; o.ld_resid = ld_resid; }
+    EpiFold c;
+    c.ln_stats = f.stat; c.ln_c1 = f.c1f; c.ln_nseg = nseg; c.ln_fold_eps = 1e-5f;
+    return gemm_f32_fold(o, c, s);
+}
+
 static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
                       float* traj, void* ws, hipStream_t s) {
     const int D = w->D, H = w->H, L = w->L;
@@ -115,6 +166,8 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
     SplitkScope sk(f.sk, kSplitkBytes);
     VITA_TRY(launch_step_times(f.ts, K, s));
     VITA_TRY(time_path(w, f, K, s));
+    const bool fold = f.stat != nullptr;
+    if (fold) VITA_TRY(fold_tables(w, f, K, s));
     const float dt = (float)(1.0 / (double)K);  // python float 1.0/num_steps, rounded to fp32 at the multiply
     if (traj)
         VITA_CHECK_HIP(hipMemcpy2DAsync(traj, (size_t)D * 4, x0, (size_t)ldx0 * 4, (size_t)D * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
@@ -124,7 +177,8 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
         float* dst = traj ? traj + (size_t)(k + 1) * B * D : x_out;
         const int64_t ldd = traj ? D : ldo;
         const float* mod = f.mod + (size_t)k * L * 3 * H;
-        VITA_TRY(flow_eval(w, f, src, lds, mod, 0, dst, ldd, src, lds, dt, B, s));
+        if (fold) VITA_TRY(flow_eval_folded(w, f, src, lds, mod, k, dst, ldd, src, lds, dt, B, s));
+        else VITA_TRY(flow_eval(w, f, src, lds, mod, 0, dst, ldd, src, lds, dt, B, s));
         src = dst;
         lds = ldd;
     }

@@ -292,6 +292,77 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
     return VITA_OK;
 }
 
+// ---- tables of the folded LayerNorm (vita_api.hip) --------------------------------------------
+// One wave per weight row j of one "layer" (blockIdx.y): rs = sum_i W[j][i]; for each of the K modulation vectors
+// c1[k][j] = sum_i mul_k[i] W[j][i] (+ rs), c2[k][j] = sum_i add_k[i] W[j][i] + bias[j].  The weight row stays in registers
+// (H <= 2048), the per-lane partial dot products of 4 vectors are formed before their reductions.  Deterministic.
+struct FoldTableJob { const float* W; const float* bias; const float* mul; const float* add; float* c1; float* c2; int N; int K; int add_one; int64_t ld_vec, ld_c; };
+struct FoldTableJobs { FoldTableJob j[VITA_MAX_LAYERS + 1]; };
+
+__global__ __launch_bounds__(256) void ln_fold_tables_kernel(FoldTableJobs jobs, int H) {
+    const FoldTableJob& jb = jobs.j[blockIdx.y];
+    const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= jb.N) return;
+    const float* wr = jb.W + (int64_t)j * H;
+    const int nch = (H + 255) / 256;           // float4 chunks per lane
+    f32x4 w[8];
+    float rs = 0.f;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        w[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int i = (c * 64 + lane) * 4;
+        if (c < nch && i < H) w[c] = *reinterpret_cast<const f32x4*>(wr + i);
+        rs += (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
+    }
+    rs = wave_sum(rs);
+    const float bj = jb.bias ? jb.bias[j] : 0.f;
+    for (int k0 = 0; k0 < jb.K; k0 += 4) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, b[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (k0 + u >= jb.K) break;
+            const float* mk = jb.mul + (int64_t)(k0 + u) * jb.ld_vec;
+            const float* ak = jb.add + (int64_t)(k0 + u) * jb.ld_vec;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int i = (c * 64 + lane) * 4;
+                if (c < nch && i < H) {
+                    const f32x4 m4 = *reinterpret_cast<const f32x4*>(mk + i), a4 = *reinterpret_cast<const f32x4*>(ak + i);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[u] = fmaf(m4[e], w[c][e], a[u]); b[u] = fmaf(a4[e], w[c][e], b[u]); }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { a[u] = wave_sum(a[u]); b[u] = wave_sum(b[u]); }
+        if (lane == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (k0 + u >= jb.K) break;
+                jb.c1[(int64_t)(k0 + u) * jb.ld_c + j] = jb.add_one ? a[u] + rs : a[u];
+                jb.c2[(int64_t)(k0 + u) * jb.ld_c + j] = b[u] + bj;
+            }
+        }
+    }
+}
+
+// all layers' fc1 tables + the final (norm -> out_proj) table in one launch.  H % 4 == 0, 16-byte aligned rows.
+int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s) {
+    const int H = w->H, FF = w->FF, L = w->L;
+    VITA_REQUIRE(H <= 2048 && H % 4 == 0, "ln_fold_tables: H=%d out of range", H);
+    FoldTableJobs jobs{};
+    int nmax = w->D;
+    for (int l = 0; l < L; ++l) {
+        jobs.j[l] = FoldTableJob{w->fc1_w[l], w->fc1_b[l], mod + (size_t)l * 3 * H + H, mod + (size_t)l * 3 * H + 2 * H,
+                                 c1 + (size_t)l * FF, c2 + (size_t)l * FF, FF, T, 1, (int64_t)L * 3 * H, (int64_t)L * FF};
+        if (FF > nmax) nmax = FF;
+    }
+    jobs.j[L] = FoldTableJob{w->out_w, w->out_b, w->norm_w, w->norm_b, c1f, c2f, w->D, 1, 0, 0, (int64_t)w->D};
+    hipLaunchKernelGGL(ln_fold_tables_kernel, dim3((nmax + 3) / 4, L + 1), dim3(256), 0, s, jobs, H);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
 // ---- sinusoidal embedding --------------------------------------------------------------------
 __global__ __launch_bounds__(EW_THREADS) void sinusoid_kernel(const float* __restrict__ t, float* __restrict__ out, int64_t ldo,
                                                             int B, int dim) {

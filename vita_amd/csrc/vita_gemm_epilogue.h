@@ -36,6 +36,14 @@ struct EpiParams {
     float* partial; int64_t ld_partial;
     // optional bf16 copy of Y (the next bf16 GEMM's A operand); Y itself may then be NULL
     uint16_t* ybf; int64_t ld_ybf;
+    // ---- LayerNorm folded into the neighbouring GEMMs (sampler at large batch, vita_api.hip; interior tiles only) ----
+    // producer side: besides Y = h, write aux_out = h * (aux_mul [+ 1]) (the next GEMM's A operand) and, per row and per
+    // 128-column tile, (mean, M2) of h over the tile's columns into stat_out[(tile_n * M + row) * 2]
+    float* aux_out; int64_t ld_aux; const float* aux_mul; int aux_add_one;
+    float* stat_out;
+    // consumer side: acc <- rstd_row * (acc - mean_row * ln_c1[col]) before bias/activation, with (mean, rstd) of the row
+    // combined from ln_nseg partials of ln_seg columns each (Chan's formula), rstd = 1/sqrt(M2/H + ln_eps)
+    const float* ln_stats; const float* ln_c1; int ln_nseg; float ln_fold_eps;
 };
 
 // k-range of a split-K launch: blockIdx.x = split * tiles + tile; the split covers k in [split*k_per_split, ...)
@@ -51,6 +59,44 @@ inline int epi_vec_ok(const EpiParams& e) {
     auto ok = [](const void* q, int64_t ld) { return q == nullptr || (epi_aligned(q) && ld % 4 == 0); };
     return ok(e.Y, e.ldy) && ok(e.bias, 0) && ok(e.gate, e.ld_gate) && ok(e.resid, e.ld_resid) && ok(e.preact, e.ld_preact) &&
            ok(e.act_grad_z, e.ld_act_grad_z) && ok(e.ybf, e.ld_ybf);
+}
+
+// Folded LayerNorm, consumer side: (mean, rstd) of row `row` from the producer's per-segment (mean, M2) partials, Chan's
+// combination of ln_nseg segments of `seg` columns each.
+__device__ __forceinline__ void fold_row_stats(const EpiParams& e, int64_t row, int seg, float* out2) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    const float* sp = e.ln_stats + row * 2;
+    const int64_t seg_stride = (int64_t)e.M * 2;
+    f32x2 part[16];   // every segment's (mean, M2) requested before the first use: one memory round trip (ln_nseg <= 16)
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) {
+        part[sg] = f32x2{0.f, 0.f};
+        if (sg < e.ln_nseg) part[sg] = *reinterpret_cast<const f32x2*>(sp + sg * seg_stride);
+    }
+    float mu = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) if (sg < e.ln_nseg) mu += part[sg][0];
+    mu = mu / (float)e.ln_nseg;
+    float m2 = 0.f;
+#pragma unroll
+    for (int sg = 0; sg < 16; ++sg) {
+        if (sg < e.ln_nseg) {
+            const float d = part[sg][0] - mu;
+            m2 += part[sg][1] + (float)seg * (d * d);
+        }
+    }
+    out2[0] = mu;
+    out2[1] = 1.0f / sqrtf(m2 / (float)(e.ln_nseg * seg) + e.ln_fold_eps);
+}
+
+// sum over each 32-lane half of the wave, result in all of its lanes: four DPP steps inside the 16-lane rows (quad
+// permutes, half mirror, mirror) and one cross-row exchange
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));   // row_mirror
+    return v + __shfl_xor(v, 16, 64);
 }
 
 template <int ACT, bool BWD>
@@ -71,7 +117,7 @@ __device__ __forceinline__ float epi_elem(float acc, float bias, float zin, floa
 // index order (deterministic).  obuf then needs KG * BM * (BN + 4) floats.
 template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD, int KG = 1>
 __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
-                                              int lane, int tid, int kg = 0) {
+                                              int lane, int tid, int kg = 0, const float* srow = nullptr) {
     constexpr int S = BN + 4;
     constexpr int TM = MI * 32, TN = NI * 32;
     constexpr int C4 = BN / 4;
@@ -144,11 +190,23 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
             f32x4 gv = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
             if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
             if (gate_vec) gv = *reinterpret_cast<const f32x4*>(e.gate + col);
+            f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, am = c1;
+            if (e.ln_stats) c1 = *reinterpret_cast<const f32x4*>(e.ln_c1 + col);
+            if (e.aux_out) {
+                am = *reinterpret_cast<const f32x4*>(e.aux_mul + col);
+                if (e.aux_add_one) am = am + 1.0f;
+            }
 #pragma unroll
             for (int it = 0; it < ITERS; ++it) {
                 const int lr = lr0 + it * RSTEP;
                 const int64_t row = m0 + lr;
-                const f32x4 a = tile_row4(lr, lc);
+                f32x4 a = tile_row4(lr, lc);
+                if (e.ln_stats) {   // folded LayerNorm: finish the normalisation on the accumulators; srow = (mean, rstd)
+                                    // of the tile's rows, combined by the kernel's prologue (fold_row_stats)
+                    const float mu = srow[lr * 2], rstd = srow[lr * 2 + 1];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = rstd * (a[k] - mu * c1[k]);
+                }
                 f32x4 zin = {0.f, 0.f, 0.f, 0.f}, rs = zin, g = gv, pre, out;
                 if constexpr (BWD) {
                     if (pf) zin = pre_z[PREFETCH ? it : 0];
@@ -172,6 +230,25 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
 #pragma unroll
                     for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(out[k]);
                     *reinterpret_cast<u16x4*>(e.ybf + row * e.ld_ybf + col) = hb;
+                }
+                if (e.aux_out) {
+                    *reinterpret_cast<f32x4*>(e.aux_out + row * e.ld_aux + col) = out * am;
+                    if constexpr (C4 == 32) {
+                        // a row's BN = 128 outputs sit in 32 consecutive lanes.  (mean, M2) in ONE shuffle chain: sums of
+                        // d = x - x0 and d^2 with x0 the row's first element (shifted one-pass: no cancellation against the mean)
+                        const float xa = __builtin_amdgcn_readlane(out[0], 0), xb = __builtin_amdgcn_readlane(out[0], 32);
+                        const float x0 = lane < 32 ? xa : xb;
+                        float sm = 0.f, q = 0.f;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { const float d = out[k] - x0; sm += d; q = fmaf(d, d, q); }
+                        sm = half_wave_sum(sm);
+                        q = half_wave_sum(q);
+                        if ((tid & 31) == 0) {
+                            float* st = e.stat_out + ((int64_t)(n0 / BN) * e.M + row) * 2;
+                            st[0] = x0 + sm * (1.0f / (float)BN);
+                            st[1] = q - sm * sm * (1.0f / (float)BN);
+                        }
+                    }
                 }
             }
             return;
@@ -236,8 +313,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
 // BACKWARD = true: the transposed-operand GEMMs (act = the activation whose derivative is applied from act_grad_z).
 template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD, int KG = 1>
 __device__ __forceinline__ void epilogue_dispatch(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
-                                                  int lane, int tid, int kg = 0) {
-#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg)
+                                                  int lane, int tid, int kg = 0, const float* srow = nullptr) {
+#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg, srow)
     if (e.partial != nullptr || (BACKWARD && e.act_grad_z == nullptr)) {
         epilogue_tile<BM, BN, MI, NI, NT_, VITA_ACT_NONE, false, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg);
         return;

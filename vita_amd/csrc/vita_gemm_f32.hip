@@ -19,6 +19,7 @@
 #include <type_traits>
 
 #include "vita_gemm_epilogue.h"
+#include "vita_host.h"
 
 namespace vita {
 
@@ -299,7 +300,7 @@ static int launch_cfg(const GemmParams& p0, hipStream_t stream) {
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
-int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
+int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk, const EpiFold* fold = nullptr);
 int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 bool gemm_f32_dma_eligible(const vita_linear_args& a);
 
@@ -394,6 +395,13 @@ static EpiParams epi_of(const vita_linear_args& a) {
     e.act_grad_z = a.act_grad_z; e.ld_act_grad_z = a.ld_act_grad_z;
     e.vec = 0;
     return e;
+}
+
+int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t stream) {
+    VITA_REQUIRE(a.X && a.W && a.Y && !a.a_col && !a.b_col && a.pro == VITA_PRO_NONE && a.preact == nullptr && a.act_grad_z == nullptr &&
+                     gemm_f32_dma_eligible(a),
+                 "gemm_f32_fold: the call is not eligible for the folded-LayerNorm epilogue");
+    return gemm_f32_dma(a, stream, nullptr, &fold);
 }
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {

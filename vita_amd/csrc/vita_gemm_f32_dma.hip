@@ -53,6 +53,7 @@ __device__ unsigned long long g_stamps[4096 * 8];
 #define VITA_EPI_STAMP(i) STAMP(i)
 
 #include "vita_gemm_epilogue.h"
+#include "vita_host.h"
 
 namespace vita {
 
@@ -120,13 +121,14 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     constexpr int NCH = BK / 8 / KG;           // 8-deep k chunks of a k-tile that one wave reduces
     constexpr int STAGE = (BM + BN) * BK;      // floats per stage
     static_assert(A_DMA >= 1 && B_DMA >= 1 && MI >= 1 && NI >= 1 && NCH >= 2 && NCH % 2 == 0 && NS >= 3 && WGM >= 1, "bad tile");
-    static_assert(KG == 1 || KG * BM * (BN + 4) <= NS * STAGE, "the k-groups' partial tiles must fit the stage buffers");
+    static_assert(KG * BM * (BN + 4) <= NS * STAGE, "the output tile(s) of the epilogue must fit the stage buffers");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // [NS][ A: BM x BK | B: BN x BK ]  then (LN only) mul[K], add[K], stats[BM][2]
     float* lnm = smem + NS * STAGE;
     float* lna = lnm + (LN ? p.K : 0);
     float* stat = lna + (LN ? p.K : 0);
+    float* sfold = stat + (LN ? 2 * BM : 0);   // folded LayerNorm (consumer): (mean, rstd) of the tile's rows, 2*BM floats
 
 #ifdef VITA_STAGGER   // lab: delay half of the workgroups so co-resident pairs are out of phase
     if ((blockIdx.x >> VITA_STAGGER_SHIFT) & 1) {
@@ -200,6 +202,10 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     // prologue DMAs first: they fly while the LayerNorm statistics are computed
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_tile(s, s);
+
+    // folded LayerNorm, consumer side: combine the producer's partial row statistics while the first DMAs fly; the barrier
+    // in front of the k-loop publishes them for the epilogue
+    if (p.epi.ln_stats != nullptr && tid < BM && m0 + tid < p.M) fold_row_stats(p.epi, m0 + tid, 128, sfold + tid * 2);
 
     // ---- LayerNorm: tables into LDS, row statistics (two-pass) ---------------------------
     float mean[MI], rstd[MI];
@@ -393,7 +399,7 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     __syncthreads();   // every wave is done reading fragments, every DMA has landed
     EpiParams e = p.epi;
     if (e.partial != nullptr) e.partial += (int64_t)split * p.M * e.ld_partial;
-    epilogue_dispatch<BM, BN, MI, NI, DNT, false, KG>(acc, smem, e, m0, n0, wm, wn, lane, tid, kg);
+    epilogue_dispatch<BM, BN, MI, NI, DNT, false, KG>(acc, smem, e, m0, n0, wm, wn, lane, tid, kg, sfold);
     STAMP(3);
     RSTAMP(5);
 }
@@ -429,7 +435,7 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
 #endif
     }
     const bool ln = p.pro != VITA_PRO_NONE;
-    const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0)) * sizeof(float);
+    const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0) + (p.epi.ln_stats ? 2 * BM : 0)) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(DNT);
     if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC, false, KG>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC, false, KG>), grid, block, lds, stream, p);
@@ -439,7 +445,7 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
 
 // Eligibility is decided by the caller (vita_gemm_f32.hip): 16-byte aligned X/W rows, K % 4 == 0,
 // LayerNorm vectors broadcast over rows (ld == 0) and K small enough for the LDS tables.
-int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) {
+int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk, const EpiFold* fold) {
     GemmParamsDma p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias;
     p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K;
@@ -455,6 +461,18 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
     p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
     p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
     p.epi.vec = epi_vec_ok(p.epi);
+    if (fold) {
+        auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+        VITA_REQUIRE(p.epi.vec && a.M % 256 == 0 && a.N % 128 == 0 && sk == nullptr && al(fold->aux_out) && al(fold->aux_mul) &&
+                         al(fold->ln_c1) && fold->ld_aux % 4 == 0,
+                     "folded LayerNorm epilogue needs interior, 16-byte aligned tiles (M=%d N=%d)", a.M, a.N);
+        VITA_REQUIRE((fold->aux_out == nullptr) == (fold->stat_out == nullptr) && (fold->aux_out == nullptr) == (fold->aux_mul == nullptr) &&
+                         (fold->ln_stats == nullptr) == (fold->ln_c1 == nullptr) && (fold->ln_stats == nullptr || fold->ln_nseg >= 1),
+                     "folded LayerNorm epilogue: inconsistent arguments");
+        p.epi.aux_out = fold->aux_out; p.epi.ld_aux = fold->ld_aux; p.epi.aux_mul = fold->aux_mul; p.epi.aux_add_one = fold->aux_add_one;
+        p.epi.stat_out = fold->stat_out; p.epi.ln_stats = fold->ln_stats; p.epi.ln_c1 = fold->ln_c1; p.epi.ln_nseg = fold->ln_nseg;
+        p.epi.ln_fold_eps = fold->ln_fold_eps;
+    }
     if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
 #ifndef VITA_DMA_CFG

@@ -6,6 +6,18 @@
 namespace vita {
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream);
+// LayerNorm folded into the neighbouring GEMMs' epilogues (see EpiParams in vita_gemm_epilogue.h).  Producer fields:
+// aux_out/aux_mul/stat_out; consumer fields: ln_stats/ln_c1.  Requires the LDS-DMA kernel, M % 256 == 0, N % 128 == 0 and
+// 16-byte aligned operands (every tile interior); returns an error otherwise.
+struct EpiFold {
+    float* aux_out = nullptr; int64_t ld_aux = 0; const float* aux_mul = nullptr; int aux_add_one = 0;
+    float* stat_out = nullptr;
+    const float* ln_stats = nullptr; const float* ln_c1 = nullptr; int ln_nseg = 0; float ln_fold_eps = 0.f;
+};
+int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t stream);
+// c-tables of the folded LayerNorm for T steps: c1[(k*L+l)*FF + j] = sum_i (1 + scale_kl[i]) W1_l[j][i], c2 likewise from the shifts
+// (+ b1); c1f/c2f (D) for norm -> out_proj.  One launch (vita_elementwise.hip).
+int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s);
 int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
 int launch_step_times(float* ts, int K, hipStream_t s);
 int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
