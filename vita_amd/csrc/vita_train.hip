@@ -168,6 +168,28 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
     out[col] = accumulate ? out[col] + s : s;
 }
 
+// few rows (M <= 2048: bias gradients of a B=128 step): ONE launch; 32 columns x 32 row lanes per block, fixed summation order
+__global__ __launch_bounds__(1024) void colsum_small_kernel(const float* __restrict__ x, int64_t ldx, int M, int N, float* __restrict__ out,
+                                                            int accumulate) {
+    const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < N) {
+        int r = rl;
+        for (; r + 32 < M; r += 64) { s0 += x[(int64_t)r * ldx + col]; s1 += x[(int64_t)(r + 32) * ldx + col]; }
+        if (r < M) s0 += x[(int64_t)r * ldx + col];
+    }
+    __shared__ float sh[32][33];
+    sh[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && col < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += sh[k][c];
+        out[col] = accumulate ? out[col] + s : s;
+    }
+}
+
 // ---- conv1d(k=5, s=2, p=2) as a GEMM: im2col / col2im on channels-last activations ------------------
 // x (B, Lin, C) -> col (B*Lout, C*5), col[(b,lo), c*5+kk] = x[b, 2*lo+kk-2, c] (0 outside), so the
 // checkpoint weight (Cout, Cin, 5) viewed as (Cout, Cin*5) is used unchanged (action_ae.py:303-305).
@@ -359,6 +381,10 @@ int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy
 int64_t vita_colsum_partials_count(int32_t N) { return (int64_t)CS_R * (N > 0 ? N : 0); }
 int vita_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* partials, float* out, int32_t accumulate, vita_stream_t s) {
     VITA_REQUIRE(x && partials && out && M >= 0 && N > 0 && ldx >= N, "vita_colsum_f32: bad arguments");
+    if (M <= 2048) {
+        hipLaunchKernelGGL(colsum_small_kernel, dim3((N + 31) / 32), dim3(1024), 0, (hipStream_t)s, x, ldx, M, N, out, accumulate);
+        LAUNCH_OK();
+    }
     hipLaunchKernelGGL(colsum_stage1, dim3((N + 63) / 64, CS_R), dim3(256), 0, (hipStream_t)s, x, ldx, M, N, partials);
     hipLaunchKernelGGL(colsum_stage2, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)s, partials, N, out, accumulate);
     LAUNCH_OK();
