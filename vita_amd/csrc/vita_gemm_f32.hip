@@ -321,11 +321,20 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(EpiParams e, const f
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
         const int row = (int)(i / c4), col = (int)(i - (int64_t)row * c4) * 4;
         const float* src = part + (int64_t)row * ldp + col;
+        // partials are requested 8 at a time before any is added (a latency-bound kernel: one round trip per 8 splits
+        // instead of one per split); the additions keep the index order
         f32x4 a = *reinterpret_cast<const f32x4*>(src);
-        for (int s2 = 1; s2 < S; ++s2) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(src + s2 * split_stride);
+        for (int s0 = 1; s0 < S; s0 += 8) {
+            f32x4 b[8];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) a[k] = a[k] + b[k];
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < S) b[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(s0 + u) * split_stride);
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (s0 + u < S) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) a[k] = a[k] + b[u][k];
+                }
         }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
