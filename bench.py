@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--train-batch", type=int, default=128, help="training rows per GPU (default_policy.yaml:34)")
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0 = same as --steps)")
     ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-large-batch", type=int, default=4096, help="N=1 only: side figures of the training step at this batch, fp32 and bf16 operands (0 = skip)")
     ap.add_argument("--cpu-rows", type=int, default=512)
     args = ap.parse_args()
 
@@ -138,22 +139,19 @@ def main():
                 "normalised_max_error_vs_f32_path": float(f"{err:.3g}"), "stated_tolerance": 2e-2}
 
     # ---- training leg: data-parallel train_step (normalize -> fused fwd+bwd -> bucketed all-reduce -> clip+AdamW+EMA)
-    train = None
-    if not args.no_train and args.hidden != 512:
-        print("bench.py: the training leg uses the default policy dims; skipped for --hidden != 512", file=sys.stderr)
-    if not args.no_train and args.hidden == 512:
+    def train_leg(TB, gemm_dtype, nts, all_ranks):
         from vita_amd.config import default_config
         from vita_amd.policy import VitaPolicy
         from vita_amd.trainer import PolicyTrainer
         cfg = default_config(args.task)
         cfg.policy.flow_matcher.name = "conditional"     # identity pairing for timing; the OT draw is host work
+        cfg.policy.gemm_dtype = gemm_dtype
         S = cfg.task.state_dim
         stats = {cfg.task.state_key: {"mean": [0.0] * S, "std": [1.0] * S}, cfg.task.action_key: {"mean": [0.0] * A, "std": [1.0] * A}}
         torch.manual_seed(0)
         pol = VitaPolicy(cfg, stats)
         pol.load_state_dict({k: v for k, v in sd.items()}, strict=False)
         tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100000)
-        TB = args.train_batch
         gt = torch.Generator().manual_seed(100 + rank)
         ncam = len(cfg.task.image_keys)
         tbatch = {cfg.task.state_key: torch.randn(TB, 1, S, generator=gt).to(dev),
@@ -163,14 +161,14 @@ def main():
         tr.step_counter = 1000                           # past the lr warm-up, so the update is not a no-op
         for i in range(3):
             tr.train_step(tbatch, t=tts[i % 64])
-        fence()
-        nts = args.train_steps or args.steps
+        fence() if all_ranks else torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         for i in range(nts):
             tr.train_step(tbatch, t=tts[i % 64])
-        fence()
+        fence() if all_ranks else torch.cuda.synchronize(dev)
         tel = time.perf_counter() - t0
-        if dist is not None:
+        w_ = world if all_ranks else 1
+        if dist is not None and all_ranks:
             tt = torch.tensor([tel], device=dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             tel = tt.item()
@@ -178,17 +176,30 @@ def main():
         f_train = 3 * (2 * obs_dim * fw.D + 19_734_528 + (2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D + 7_864_320)
                        + K * (2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D)
                        + 2 * (2 * fw.D * dw.HD + dw.w.NL * 4 * dw.HD * dw.HD + 2 * dw.HD * dw.OUT)) if args.task == "hook_package" else None
-        train = {"metric": "train samples/sec", "value": round(world * TB * nts / tel, 1), "unit": "samples/s",
-                 "ms_per_step": round(tel * 1e3 / nts, 4), "steps": nts, "batch_per_gpu": TB, "global_batch": TB * world,
-                 "dtype": "f32", "loss": round(m["loss"], 6), "grad_norm": round(m["grad_norm"], 6),
-                 "grad_bytes_allreduced_per_step": int(tr.flat_grad.numel() * 4) if world > 1 else 0,
-                 "parallelism": f"data-parallel x{world}, 3 event-driven gradient buckets over RCCL" if world > 1 else "single GPU",
-                 "includes": "normalize, fused forward+backward (1 FM eval + K Euler steps + encoder + 2 decodes), grad-norm clip, AdamW, EMA; observer excluded (camera latents are the input)",
-                 "algorithmic_flops_per_sample_fwd_bwd": f_train}
+        res = {"metric": "train samples/sec", "value": round(w_ * TB * nts / tel, 1), "unit": "samples/s",
+               "ms_per_step": round(tel * 1e3 / nts, 4), "steps": nts, "batch_per_gpu": TB, "global_batch": TB * w_,
+               "dtype": "f32" if gemm_dtype == "f32" else "bf16 GEMM operands (calls >= 2^31 FLOP), f32 accumulate / master weights / gradients",
+               "loss": round(m["loss"], 6), "grad_norm": round(m["grad_norm"], 6),
+               "grad_bytes_allreduced_per_step": int(tr.flat_grad.numel() * 4) if w_ > 1 else 0,
+               "parallelism": f"data-parallel x{w_}, 3 event-driven gradient buckets over RCCL" if w_ > 1 else "single GPU",
+               "includes": "normalize, fused forward+backward (1 FM eval + K Euler steps + encoder + 2 decodes), grad-norm clip, AdamW, EMA; observer excluded (camera latents are the input)",
+               "algorithmic_flops_per_sample_fwd_bwd": f_train}
         if f_train:
-            train["tflops"] = round(train["value"] * f_train / 1e12 / world, 2)
-            train["frac_of_f32_mfma_peak"] = round(train["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
+            res["tflops"] = round(res["value"] * f_train / 1e12 / w_, 2)
+            res["frac_of_f32_mfma_peak"] = round(res["tflops"] / PEAK_F32_MFMA_TFLOPS, 4)
         del tr, pol
+        return res
+
+    train = train_large = train_large_bf16 = None
+    if not args.no_train and args.hidden != 512:
+        print("bench.py: the training leg uses the default policy dims; skipped for --hidden != 512", file=sys.stderr)
+    if not args.no_train and args.hidden == 512:
+        train = train_leg(args.train_batch, "f32", args.train_steps or args.steps, True)
+        if world == 1 and args.train_large_batch > 0:
+            # side figures at a batch that fills the chip: fp32, and BASELINE configs[2]'s bf16-operand training
+            train_large = train_leg(args.train_large_batch, "f32", 5, False)
+            train_large_bf16 = train_leg(args.train_large_batch, "bf16", 5, False)
+            train_large_bf16["loss_rel_diff_vs_f32"] = float(f"{abs(train_large_bf16['loss'] - train_large['loss']) / abs(train_large['loss']):.3g}")
 
     # ---- per-kernel roofline: HIP events around the dominant GEMM classes, on the launch stream
     def time_linear(M, N, Kd, reps=20, **kw):
@@ -282,6 +293,8 @@ def main():
                                    "dependent kernels; rocprofv3's per-kernel duration (profiles/) excludes it, see DESIGN.md section 4"},
             "kernels": kernels,
             "train": train,
+            "train_large_batch": train_large,
+            "train_large_batch_bf16": train_large_bf16,
             "bf16_variant": bf16,
             "cpu_baseline": cpu,
         }

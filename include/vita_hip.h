@@ -280,6 +280,10 @@ typedef struct vita_encoder_weights {
     const float *w2[VITA_MAX_LAYERS], *b2[VITA_MAX_LAYERS];
     /* cnn: latent_proj (D, C*(T>>NL));  simple: input_proj (C, A) */
     const float *proj_w, *proj_b;
+    /* 1: the variational CNNActionEncoder of action_vae.py:179-229 (policy.action_ae.use_variational): latent_proj is
+     * (2D, C*(T>>NL)) and its output rows are [mean | logvar] of a DiagonalGaussianDistribution (models/dists.py:4-21);
+     * cnn only */
+    int32_t variational;
 } vita_encoder_weights;
 
 typedef struct vita_policy_weights {
@@ -303,10 +307,15 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
     int32_t freeze_encoder;        /* action_ae.freeze_encoder: action latents carry no gradient (:119), no sampler branch (:153) */
     int32_t freeze_decoder;        /* action_ae.freeze_decoder: no reconstruction terms (:174,183), no sampler branch (:153);
                                       frozen modules' gradient buffers are written as zeros */
+    float kl_weight;               /* action_ae.kl_weight: weight of posterior.kl().mean() (:146-150); variational encoders only */
+    int32_t gemm_bf16;             /* 0: fp32 MFMA GEMMs (the reference's arithmetic).  1: GEMMs of >= 2^31 FLOP run on bf16
+                                      operands (fp32 -> bf16 staged per call, fp32 accumulate / epilogue / master weights /
+                                      gradients); 2: every GEMM does.  NOT bit-comparable with fp32: stated tolerance in
+                                      tests/test_gpu_bf16_train.py (BASELINE configs[2]) */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,
-       VITA_LOSS_ENC_CONTRASTIVE = 5, VITA_LOSS_FLOW_CONTRASTIVE = 6, VITA_LOSS_COUNT = 8 };
+       VITA_LOSS_ENC_CONTRASTIVE = 5, VITA_LOSS_FLOW_CONTRASTIVE = 6, VITA_LOSS_ACTION_KL = 7, VITA_LOSS_COUNT = 8 };
 
 /* vita_compute_loss_f32 — VitaPolicy.compute_loss from observer features on (vita_policy.py:112-189, defaults: plain
  * autoencoder, nothing frozen, contrastive weights 0) followed by its backward pass (loss.backward(),
@@ -316,6 +325,10 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
  *   pred = Euler_K(z0);  L_c = mse(pred, z1);  L_fr = recon(dec(pred), actions);  L_er = recon(dec(z1), actions)
  *   loss = L_flow + cw*L_c + fw*L_fr + ew*L_er
  * `t` (B) and the OT pairing (NULL = identity) are inputs: the reference draws them on the host (torchcfm / POT).
+ * enc_noise: variational encoder only (vita_encoder_weights.variational): the (B, D) standard-normal draw of
+ *   DiagonalGaussianDistribution.sample (dists.py:20-21): z1 = mean + exp(0.5*logvar) * enc_noise, and with kl_weight > 0
+ *   and an unfrozen encoder loss += kl_weight * mean_b(0.5 * sum_c(mean^2 + var - 1 - logvar)) (:146-150).  NULL = the
+ *   deterministic posterior of eval mode (:121, dists.py:12-18,25-26): z1 = mean, KL = 0.  Must be NULL otherwise.
  * losses: device float[VITA_LOSS_COUNT], indexed by VITA_LOSS_*.
  * grads: NULL = forward only; else a descriptor of the same shape whose pointers are the gradient buffers: each
  *   is OVERWRITTEN with d loss / d weight (no zero_grad needed).  The K sampler steps and the flow-matching
@@ -327,12 +340,13 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
 size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B);
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t,
-                          const int64_t* pair_i, const int64_t* pair_j, int32_t B, float* losses,
+                          const int64_t* pair_i, const int64_t* pair_j, const float* enc_noise, int32_t B, float* losses,
                           float* d_obs_features, int64_t ld_dobs,
                           void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream);
 
 /* vita_action_encoder_forward_f32 — CNNActionEncoder.forward / SimpleActionEncoder.forward alone:
- * actions (B,T,A) contiguous -> latents (B,D). */
+ * actions (B,T,A) contiguous -> latents (B,D); the variational encoder writes its posterior's parameter rows
+ * (B,2D) = [mean | logvar] (action_vae.py:224). */
 size_t vita_action_encoder_workspace_bytes(const vita_encoder_weights* w, int32_t B);
 int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* actions, float* latents, int64_t ldl, int32_t B,
                                     void* workspace, size_t workspace_bytes, vita_stream_t stream);

@@ -220,6 +220,24 @@ def simple_action_decode(sd: SD, z: Tensor, pred_horizon: int, action_dim: int,
     return x.view(-1, pred_horizon, action_dim)
 
 
+def vae_cnn_action_encode(sd: SD, actions: Tensor, eps: Tensor | None, prefix: str = "action_encoder."):
+    """Variational CNNActionEncoder.forward, action_vae.py:217-229: the same conv trunk with a (2*latent_dim)-wide
+    latent_proj, then DiagonalGaussianDistribution (models/dists.py:4-21): mean, logvar = chunk(params, 2, dim=1);
+    sample = mean + exp(0.5*logvar) * eps, eps = randn_like(mean) (an input here); eps None = deterministic (:12-18):
+    sample = mean.  Returns (mean, logvar, z)."""
+    params = cnn_action_encode(sd, actions, prefix)
+    mean, logvar = torch.chunk(params, 2, dim=1)
+    if eps is None:
+        return mean, logvar, mean
+    std = torch.exp(0.5 * logvar)
+    return mean, logvar, mean + std * eps
+
+
+def is_variational(sd: SD) -> bool:
+    w = sd.get("action_encoder.latent_proj.weight")
+    return w is not None and w.shape[0] == 2 * sd["obs_encoder.weight"].shape[0]
+
+
 def action_encode(sd: SD, actions: Tensor) -> Tensor:
     if "action_encoder.latent_proj.weight" in sd:
         return cnn_action_encode(sd, actions)
@@ -361,9 +379,12 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
                  flow_recon_weight: float = 0.5, recon_loss_type: str = "l1",
                  enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
                  decode_flow_latents: bool = True, sigma: float = 0.0,
-                 freeze_encoder: bool = False, freeze_decoder: bool = False):
+                 freeze_encoder: bool = False, freeze_decoder: bool = False,
+                 kl_weight: float = 0.0, enc_noise: Tensor | None = None):
     """VitaPolicy.compute_loss, vita_policy.py:112-189, from observer features on, with the
-    default non-variational autoencoder and the freeze flags of :119,142-143,153,174,183.
+    freeze flags of :119,142-143,153,174,183.  A state dict whose action_encoder.latent_proj is
+    2*latent_dim wide is the variational autoencoder (use_variational, :120-121,146-150):
+    `enc_noise` is the posterior's randn_like draw (None = eval mode's deterministic posterior).
     Returns (loss, metrics) where metrics holds 0-dim tensors (the reference calls .item()
     on each)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
@@ -371,7 +392,11 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
     B = obs_features.shape[0]
     m = {}
     obs_latents = obs_encode(sd, obs_features)                                  # :114
-    action_latents = action_encode(sd, gt_actions)                              # :123
+    vae = is_variational(sd)
+    if vae:                                                                     # :121
+        post_mean, post_logvar, action_latents = vae_cnn_action_encode(sd, gt_actions, enc_noise)
+    else:
+        action_latents = action_encode(sd, gt_actions)                          # :123
     if freeze_encoder:                                                          # :119 torch.no_grad()
         action_latents = action_latents.detach()
     flow_loss = fm_loss(sd, obs_latents, action_latents, t, pair_i, pair_j, sigma)  # :126-130
@@ -384,6 +409,13 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
     if freeze_encoder and freeze_decoder:                                       # :142-143
         m["loss"] = loss
         return loss, m
+    if not freeze_encoder and vae and kl_weight > 0:                            # :146-150
+        if enc_noise is None:                                                   # dists.py:25-26
+            kl = torch.zeros((), dtype=obs_latents.dtype)
+        else:
+            kl = gaussian_kl(post_mean, post_logvar)
+        m["action_kl_loss"] = kl
+        loss = loss + kl_weight * kl
     if decode_flow_latents and not freeze_encoder and not freeze_decoder:       # :153-178
         pred = euler_sample(sd, obs_latents, num_steps)
         if consistency_weight > 0:
@@ -453,7 +485,7 @@ def adamw_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float,
 def make_state_dict(obs_dim: int, action_dim: int, latent_dim: int = 512, hidden_dim: int = 512,
                     num_layers: int = 4, mlp_ratio: int = 4, pred_horizon: int = 16,
                     ae_hidden: int = 512, ae_layers: int = 4, time_embed_dim: int = 256,
-                    encoder_type: str = "cnn", seed: int = 0, dtype=torch.float32) -> SD:
+                    encoder_type: str = "cnn", seed: int = 0, dtype=torch.float32, variational: bool = False) -> SD:
     """Seeded Xavier-like weights with the reference's state-dict keys and shapes
     (SURVEY.md 8(b)).  Biases and the modulators are NOT zero so every term is exercised."""
     g = torch.Generator().manual_seed(seed)
@@ -487,7 +519,7 @@ def make_state_dict(obs_dim: int, action_dim: int, latent_dim: int = 512, hidden
                 torch.randn(ae_hidden, generator=g, dtype=torch.float64) * 0.02).to(dtype)
             cin = ae_hidden
         conv_len = pred_horizon // (2 ** ae_layers)
-        lin("action_encoder.latent_proj", D, ae_hidden * conv_len)
+        lin("action_encoder.latent_proj", 2 * D if variational else D, ae_hidden * conv_len)   # action_vae.py:213
     else:
         ald = D // pred_horizon
         lin("action_encoder.input_proj", ald, action_dim)

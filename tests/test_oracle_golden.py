@@ -151,3 +151,24 @@ def test_alternate_matchers_inference(alt):
     for K in (1, 4):
         close(O.consistency_sample(sd, alt["cfm/x0"], K, sigma_var=0.0), alt[f"cfm/det/K{K}"])
         close(O.consistency_sample(sd, alt["cfm/x0"], K, noise=alt[f"cfm/sde/noise{K}"]), alt[f"cfm/sde/K{K}"])
+
+
+def test_vae_branch_losses_and_gradients_match_reference_autograd(golden_dir):
+    """Variational encoder branch (action_vae.py:179-229, dists.py, vita_policy.py:120-121,146-150): the oracle against
+    the losses and gradients the reference's own modules + autograd produced (tools/gen_golden_vae.py)."""
+    v = load(os.path.join(golden_dir, "vae.safetensors"))
+    tag = "vae_A7"
+    p = tag + "/sd/"
+    sd = {k[len(p):]: x for k, x in v.items() if k.startswith(p)}
+    obs, actions, t, eps = (v[f"{tag}/{k}"] for k in ("obs_features", "actions", "t", "eps"))
+    mean, logvar, z = O.vae_cnn_action_encode(sd, actions, eps)
+    close(mean, v[tag + "/mean"]); close(logvar, v[tag + "/logvar"]); close(z, v[tag + "/z"])
+    for name, klw, training in (("kl1e-4", 1e-4, True), ("kl0.1", 0.1, True), ("eval", 0.1, False)):
+        sdg = {k: x.clone().requires_grad_(True) for k, x in sd.items()}
+        loss, m = O.compute_loss(sdg, obs, actions, t, 6, kl_weight=klw, enc_noise=eps if training else None)
+        for k in m:
+            close(m[k].detach().reshape(1), v[f"{tag}/{name}/loss/{k}"], 3e-6)
+        keys = list(sdg)
+        gs = torch.autograd.grad(loss, [sdg[k] for k in keys])
+        for k, g in zip(keys, gs):
+            close(g, v[f"{tag}/{name}/grad/{k}"], 2e-5)

@@ -82,6 +82,7 @@ class EncoderWeights(C.Structure):
         ("kind", C.c_int32), ("A", C.c_int32), ("T", C.c_int32), ("C", C.c_int32), ("NL", C.c_int32), ("D", C.c_int32),
         ("w1", _PA), ("b1", _PA), ("w2", _PA), ("b2", _PA),
         ("proj_w", c_fp), ("proj_b", c_fp),
+        ("variational", C.c_int32),
     ]
 
 
@@ -101,6 +102,7 @@ class LossConfig(C.Structure):
         ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
+        ("kl_weight", C.c_float), ("gemm_bf16", C.c_int32),
     ]
 
 
@@ -115,7 +117,7 @@ class Bf16Weights(C.Structure):
 
 ENC_CNN, ENC_SIMPLE = 0, 1
 LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "enc_contrastive_loss",
-              "flow_contrastive_loss")
+              "flow_contrastive_loss", "action_kl_loss")
 LOSS_COUNT = 8
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
@@ -152,7 +154,7 @@ SIGNATURES = {
                                                   C.c_float, C.c_int32, c_fp, C.c_int64, C.c_int32, c_fp, c_fp, C.c_int64, c_fp]),
     "vita_compute_loss_workspace_bytes": (C.c_size_t, [C.POINTER(PolicyWeights), C.POINTER(LossConfig), C.c_int32]),
     "vita_compute_loss_f32": (C.c_int, [C.POINTER(PolicyWeights), C.POINTER(PolicyWeights), C.POINTER(LossConfig), c_fp, C.c_int64,
-                                        c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp, C.c_int64, C.POINTER(c_fp), c_fp,
+                                        c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp, C.c_int64, C.POINTER(c_fp), c_fp,
                                         C.c_size_t, c_fp]),
     "vita_action_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderWeights), C.c_int32]),
     "vita_action_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderWeights), c_fp, c_fp, C.c_int64, C.c_int32, c_fp, C.c_size_t,

@@ -107,6 +107,46 @@ __global__ __launch_bounds__(CT) void kl_bwd_kernel(const float* __restrict__ me
     }
 }
 
+// DiagonalGaussianDistribution.sample (models/dists.py:16-21) on params rows [mean | logvar]: z = mean + exp(0.5*logvar) * eps;
+// eps == NULL is the deterministic posterior (:12-18): z = mean.
+__global__ __launch_bounds__(CT) void gauss_sample_kernel(const float* __restrict__ params, int64_t ldp, const float* __restrict__ eps,
+                                                         float* __restrict__ z, int64_t ldz, int B, int D) {
+    const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * CT;
+    for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const float mu = params[(int64_t)r * ldp + c];
+        float v = mu;
+        if (eps) {
+            const float sd = expf(0.5f * params[(int64_t)r * ldp + D + c]);
+            v = mu + sd * eps[i];
+        }
+        z[(int64_t)r * ldz + c] = v;
+    }
+}
+// its backward joined with the KL term's: dmean = dz + ks*mean, dlogvar = dz*eps*std*0.5 + ks*0.5*(exp(logvar) - 1),
+// ks = kl_weight / B (0: no KL term).  Deterministic posterior: dmean = dz, dlogvar = 0.
+__global__ __launch_bounds__(CT) void gauss_sample_bwd_kernel(const float* __restrict__ params, int64_t ldp, const float* __restrict__ eps,
+                                                             const float* __restrict__ dz, int64_t ld_dz, float ks, float* __restrict__ dparams,
+                                                             int64_t ld_dp, int B, int D) {
+    const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * CT;
+    for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const float g = dz[(int64_t)r * ld_dz + c];
+        float dm = g, dv = 0.f;
+        if (eps) {
+            const float mu = params[(int64_t)r * ldp + c], lv = params[(int64_t)r * ldp + D + c];
+            const float sd = expf(0.5f * lv);
+            dv = (g * eps[i]) * sd * 0.5f;
+            if (ks != 0.f) {
+                dm = dm + mu * ks;
+                dv = dv + 0.5f * (expf(lv) - 1.0f) * ks;
+            }
+        }
+        dparams[(int64_t)r * ld_dp + c] = dm;
+        dparams[(int64_t)r * ld_dp + D + c] = dv;
+    }
+}
+
 __global__ __launch_bounds__(CT) void axpy_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * CT;
     for (int64_t i = (int64_t)blockIdx.x * CT + threadIdx.x; i < n; i += stride) y[i] += x[i];
@@ -114,6 +154,22 @@ __global__ __launch_bounds__(CT) void axpy_kernel(const float* __restrict__ x, f
 
 }  // namespace
 
+int launch_gauss_sample(const float* params, int64_t ldp, const float* eps, float* z, int64_t ldz, int B, int D, hipStream_t s) {
+    if (B <= 0) return VITA_OK;
+    const int64_t blocks = ((int64_t)B * D + CT - 1) / CT;
+    hipLaunchKernelGGL(gauss_sample_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(CT), 0, s, params, ldp, eps, z, ldz, B, D);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+int launch_gauss_sample_bwd(const float* params, int64_t ldp, const float* eps, const float* dz, int64_t ld_dz, float kl_scale, float* dparams,
+                            int64_t ld_dp, int B, int D, hipStream_t s) {
+    if (B <= 0) return VITA_OK;
+    const int64_t blocks = ((int64_t)B * D + CT - 1) / CT;
+    hipLaunchKernelGGL(gauss_sample_bwd_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(CT), 0, s, params, ldp, eps, dz, ld_dz,
+                       kl_scale, dparams, ld_dp, B, D);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
 int launch_axpy(const float* x, float* y, int64_t n, hipStream_t s) {
     if (n <= 0) return VITA_OK;
     const int64_t blocks = (n + CT - 1) / CT;

@@ -396,6 +396,91 @@ __global__ __launch_bounds__(EW_THREADS) void pack_bf16_kernel(const float* __re
     }
 }
 
+// ---- operand staging of the bf16-operand training GEMMs (gemm_f32 under a Bf16Scope, vita_gemm_f32.hip) ----
+// fp32 (rows, cols) -> bf16 (rows, ld_dst), eight elements per thread (two 16-byte loads, one 16-byte store); columns
+// cols..ld_dst-1 zero-filled.  Needs 16-byte aligned src rows (ld_src % 4 == 0) and ld_dst % 8 == 0.
+typedef uint16_t u16x8 __attribute__((ext_vector_type(8)));
+__global__ __launch_bounds__(EW_THREADS) void pack_bf16_vec8_kernel(const float* __restrict__ src, int64_t ld_src, uint16_t* __restrict__ dst,
+                                                                  int64_t ld_dst, int64_t rows, int cols) {
+    const int64_t c8 = ld_dst / 8, n = rows * c8, stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const int64_t r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        const float* sp = src + r * ld_src + c;
+        u16x8 o;
+        if (c + 8 <= cols) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(sp), b = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { o[j] = f32_to_bf16(a[j]); o[4 + j] = f32_to_bf16(b[j]); }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (c + j < cols) ? f32_to_bf16(sp[j]) : (uint16_t)0;
+        }
+        *reinterpret_cast<u16x8*>(dst + r * ld_dst + c) = o;
+    }
+}
+
+// fp32 src (K rows, M cols) -> bf16 dst (M rows, ld_dst), dst[m][k] = src[k][m], k in [K, ld_dst) zero-filled: a column
+// operand of a backward GEMM (dY^T, X^T, W^T) becomes the k-contiguous rows the LDS-DMA kernel reads.  64 x 64 tiles
+// through LDS: 16-byte loads along m, 8-byte stores along k.
+template <bool VEC>
+__global__ __launch_bounds__(256) void pack_bf16_t_kernel(const float* __restrict__ src, int64_t ld_src, uint16_t* __restrict__ dst,
+                                                         int64_t ld_dst, int K, int M) {
+    __shared__ float tile[64][65];
+    const int tid = threadIdx.x, m0 = blockIdx.x * 64, k0 = blockIdx.y * 64;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256, kr = idx >> 4, mc = (idx & 15) * 4;
+        const int k = k0 + kr, m = m0 + mc;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < K) {
+            const float* sp = src + (int64_t)k * ld_src + m;
+            if constexpr (VEC) {
+                if (m < M) v = *reinterpret_cast<const f32x4*>(sp);      // M % 4 == 0: the four columns exist together
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (m + j < M) v[j] = sp[j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) tile[kr][mc + j] = v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 256, kq = (idx & 15) * 4, mr = idx >> 4;
+        const int m = m0 + mr, k = k0 + kq;
+        if (m < M && k < ld_dst) {      // ld_dst % 8 == 0 and k % 4 == 0: the four k exist together
+            u16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = f32_to_bf16(tile[kq + j][mr]);
+            *reinterpret_cast<u16x4*>(dst + (int64_t)m * ld_dst + k) = o;
+        }
+    }
+}
+
+int launch_pack_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int cols, hipStream_t s) {
+    if (rows <= 0) return VITA_OK;
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && ld_src % 4 == 0 && ld_dst % 8 == 0 &&
+                     (reinterpret_cast<uintptr_t>(dst) & 15u) == 0;
+    if (vec) hipLaunchKernelGGL(pack_bf16_vec8_kernel, dim3(ew_grid(rows * (ld_dst / 8), 4096)), dim3(EW_THREADS), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+    else hipLaunchKernelGGL(pack_bf16_kernel, dim3(ew_grid(rows * ld_dst, 4096)), dim3(EW_THREADS), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+// src (K, M) row stride ld_src -> dst (M, ld_dst) bf16, ld_dst % 8 == 0, dst 16-byte aligned
+int launch_pack_bf16_t(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int K, int M, hipStream_t s) {
+    if (K <= 0 || M <= 0) return VITA_OK;
+    VITA_REQUIRE(ld_dst % 8 == 0 && ld_dst >= K && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0, "pack_bf16_t: bad destination");
+    const dim3 grid((unsigned)((M + 63) / 64), (unsigned)((ld_dst + 63) / 64));
+    VITA_REQUIRE(grid.y <= 65535u, "pack_bf16_t: K too large (%d)", K);
+    const bool vec = (reinterpret_cast<uintptr_t>(src) & 15u) == 0 && ld_src % 4 == 0 && M % 4 == 0;
+    if (vec) hipLaunchKernelGGL((pack_bf16_t_kernel<true>), grid, dim3(256), 0, s, src, ld_src, dst, ld_dst, K, M);
+    else hipLaunchKernelGGL((pack_bf16_t_kernel<false>), grid, dim3(256), 0, s, src, ld_src, dst, ld_dst, K, M);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
 int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s) {
     VITA_REQUIRE(t && out, "vita_sinusoidal_embed_f32: null pointer");
     VITA_REQUIRE(dim >= 4 && dim % 2 == 0 && ldo >= dim, "vita_sinusoidal_embed_f32: dim must be even and >= 4, ldo >= dim");

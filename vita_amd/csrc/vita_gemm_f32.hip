@@ -406,6 +406,38 @@ static EpiParams epi_of(const vita_linear_args& a) {
     return e;
 }
 
+// bf16-operand route (training step with vita_loss_config.gemm_bf16): stage A(m,k) and B(n,k) as bf16 rows (transposing
+// column operands), run the bf16 LDS-DMA kernel with the call's own epilogue (incl. act'(z) of the backward GEMMs and
+// split-K).  *taken = false: the call is not eligible and takes the fp32 kernels.
+static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool* taken) {
+    *taken = false;
+    const Bf16Stage& st = bf16_stage();
+    if (st.mode == 0 || st.ptr == nullptr || a.pro != VITA_PRO_NONE || a.M <= 0 || a.N <= 0 || a.K <= 0) return VITA_OK;
+    if (st.mode == 1 && 2.0 * (double)a.M * (double)a.N * (double)a.K < kBf16MinFlops) return VITA_OK;
+    const int Kp = (a.K + 7) & ~7;
+    const size_t abytes = ((size_t)a.M * Kp * 2 + 255) & ~size_t(255), bbytes = ((size_t)a.N * Kp * 2 + 255) & ~size_t(255);
+    if (abytes + bbytes > st.bytes) return VITA_OK;
+    VITA_REQUIRE(a.ldx >= (a.a_col ? a.M : a.K) && a.ldw >= (a.b_col ? a.N : a.K) && a.ldy >= a.N, "vita_linear (bf16 route): leading dimension too small");
+    VITA_REQUIRE(a.act >= VITA_ACT_NONE && a.act <= VITA_ACT_MISH, "vita_linear (bf16 route): unknown activation %d", a.act);
+    uint16_t* xa = static_cast<uint16_t*>(st.ptr);
+    uint16_t* wb = reinterpret_cast<uint16_t*>(static_cast<char*>(st.ptr) + abytes);
+    if (a.a_col) VITA_TRY_RC(launch_pack_bf16_t(a.X, a.ldx, xa, Kp, a.K, a.M, stream));
+    else VITA_TRY_RC(launch_pack_bf16(a.X, a.ldx, xa, Kp, a.M, a.K, stream));
+    if (a.b_col) VITA_TRY_RC(launch_pack_bf16_t(a.W, a.ldw, wb, Kp, a.K, a.N, stream));
+    else VITA_TRY_RC(launch_pack_bf16(a.W, a.ldw, wb, Kp, a.N, a.K, stream));
+    vita_linear_args b = a;
+    b.X = reinterpret_cast<const float*>(xa); b.ldx = Kp; b.W = reinterpret_cast<const float*>(wb); b.ldw = Kp; b.K = Kp;
+    b.a_col = 0; b.b_col = 0;
+    if (!(a.a_col || a.b_col)) { b.act_grad_z = nullptr; }
+    vita_linear_args u = b;
+    u.K = Kp / 2;                               // the kernel counts k in 4-byte units (bf16 pairs)
+    const SplitK sk = plan_splitk(u);
+    VITA_TRY_RC(gemm_bf16_dma(b, nullptr, 0, stream, sk.splits > 1 ? &sk : nullptr));
+    if (sk.splits > 1) VITA_TRY_RC(launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream));
+    *taken = true;
+    return VITA_OK;
+}
+
 int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t stream) {
     VITA_REQUIRE(a.X && a.W && a.Y && !a.a_col && !a.b_col && a.pro == VITA_PRO_NONE && a.preact == nullptr && a.act_grad_z == nullptr &&
                      gemm_f32_dma_eligible(a),
@@ -416,6 +448,11 @@ int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t st
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     if (a.M == 0 && a.N > 0 && a.K > 0) return VITA_OK;  // empty batch: nothing to do (pointers may be null)
     VITA_REQUIRE(a.X && a.W && a.Y, "vita_linear_f32: X, W and Y must be non-null");
+    if (bf16_stage().mode != 0) {
+        bool taken = false;
+        VITA_TRY_RC(gemm_f32_via_bf16(a, stream, &taken));
+        if (taken) return VITA_OK;
+    }
     if (a.a_col || a.b_col) {
         const SplitK sk = (a.M > 0 && a.K > 0) ? plan_splitk(a) : SplitK{};
         VITA_TRY_RC(gemm_f32_t(a, stream, sk.splits > 1 ? &sk : nullptr));

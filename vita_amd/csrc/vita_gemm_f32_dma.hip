@@ -108,7 +108,8 @@ __device__ __forceinline__ int swz(int r) {
 // KG: in-workgroup split-K.  The 8 waves form KG groups of 8/KG; every group covers the WHOLE output tile (so a wave owns
 // KG times more of it: 64x64 instead of 32x32 at 64x128 / KG=4 -> half the LDS fragment reads per MFMA, which is what
 // bounds the small tile) and reduces 1/KG of each k-tile's chunks; the epilogue sums the groups through LDS.
-template <int BM, int BN, int BK, int NS, bool LN, int OCC, bool BF16 = false, int KG = 1>
+// BWD: the epilogue may apply act'(act_grad_z) (the backward GEMMs of the bf16-operand training step).
+template <int BM, int BN, int BK, int NS, bool LN, int OCC, bool BF16 = false, int KG = 1, bool BWD = false>
 __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p) {
     constexpr int CH = BK / 4;                 // 16-byte chunks per tile row
     constexpr int RPI = 64 / CH;               // rows covered by one DMA wave-instruction
@@ -399,7 +400,7 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     __syncthreads();   // every wave is done reading fragments, every DMA has landed
     EpiParams e = p.epi;
     if (e.partial != nullptr) e.partial += (int64_t)split * p.M * e.ld_partial;
-    epilogue_dispatch<BM, BN, MI, NI, DNT, false, KG>(acc, smem, e, m0, n0, wm, wn, lane, tid, kg, sfold);
+    epilogue_dispatch<BM, BN, MI, NI, DNT, BWD, KG>(acc, smem, e, m0, n0, wm, wn, lane, tid, kg, sfold);
     STAMP(3);
     RSTAMP(5);
 }
@@ -410,7 +411,11 @@ static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true>), dim3((unsigned)(p.tiles_m * p.tiles_n)), dim3(DNT), lds, stream, p);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1)));
+    if (p.epi.act_grad_z != nullptr)
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true, 1, true>), grid, dim3(DNT), lds, stream, p);
+    else
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true>), grid, dim3(DNT), lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
@@ -502,7 +507,8 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
 
 // bf16 operands: a.X / a.W point at bf16 data, a.K / a.ldx / a.ldw count bf16 elements (multiples of 8, 16-byte aligned
 // rows); everything on the output side is as in the fp32 call, plus the optional bf16 copy of Y.
-int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream) {
+// sk: split-K plan in the kernel's 4-byte k units (bf16 pairs), or NULL.  act_grad_z: as in the transposed fp32 GEMMs.
+int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk) {
     GemmParamsDma p{};
     p.X = a.X; p.ldx = a.ldx / 2; p.W = a.W; p.ldw = a.ldw / 2; p.bias = a.bias;
     p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K / 2;
@@ -511,8 +517,10 @@ int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipS
     p.epi.gate = a.gate; p.epi.ld_gate = a.ld_gate; p.epi.use_gate_scalar = a.use_gate_scalar;
     p.epi.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
     p.epi.resid = a.resid; p.epi.ld_resid = a.ld_resid; p.epi.preact = a.preact; p.epi.ld_preact = a.ld_preact;
+    p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
     p.epi.ybf = ybf; p.epi.ld_ybf = ld_ybf;
     p.epi.vec = epi_vec_ok(p.epi);
+    if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (t128 >= 512) return launch_dma_bf16<128, 128, 32, 4>(p, stream);
     return launch_dma_bf16<64, 128, 32, 4>(p, stream);

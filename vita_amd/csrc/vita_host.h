@@ -22,7 +22,10 @@ int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hip
 int launch_step_times(float* ts, int K, hipStream_t s);
 int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
                   int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s, uint16_t* ybf = nullptr, int64_t ld_ybf = 0);
-int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream);
+struct SplitK;
+int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk = nullptr);
+int launch_pack_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int cols, hipStream_t s);
+int launch_pack_bf16_t(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int K, int M, hipStream_t s);
 int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st);
 int launch_weighted_sum(const float* vals, const float* host_w, int n, float* out, hipStream_t st);
 
@@ -50,6 +53,20 @@ struct SplitkScope {
     SplitkScope(void* p, size_t n) : saved(splitk_scratch()) { splitk_scratch().ptr = p; splitk_scratch().bytes = n; }
     ~SplitkScope() { splitk_scratch() = saved; }
 };
+// bf16-operand training GEMMs (vita_loss_config.gemm_bf16): inside the scope gemm_f32() stages both operands of an
+// eligible call as k-contiguous bf16 rows in `ptr` (stream-ordered reuse) and runs the bf16 LDS-DMA kernel; mode 1 only
+// for calls of at least kBf16MinFlops, mode 2 for every call without a LayerNorm prologue.
+struct Bf16Stage { void* ptr = nullptr; size_t bytes = 0; int mode = 0; };
+inline Bf16Stage& bf16_stage() {
+    static thread_local Bf16Stage s;
+    return s;
+}
+struct Bf16Scope {
+    Bf16Stage saved;
+    Bf16Scope(void* p, size_t n, int mode) : saved(bf16_stage()) { bf16_stage().ptr = p; bf16_stage().bytes = n; bf16_stage().mode = mode; }
+    ~Bf16Scope() { bf16_stage() = saved; }
+};
+constexpr double kBf16MinFlops = 2147483648.0;   // 2^31: below this the two staging launches cost more than the MFMA rate gains
 constexpr size_t kSplitkBytes = size_t(32) << 20;   // == vita_splitk_workspace_bytes()
 
 inline vita_linear_args lin(const float* X, int64_t ldx, const float* W, int64_t ldw, const float* b, float* Y, int64_t ldy, int M,
@@ -101,6 +118,10 @@ int nce_forward(const float* a, int64_t lda, const float* b, int64_t ldb, int B,
 int nce_backward(int B, int D, float temperature, const float* gout, float* da, int64_t ld_da, int acc_a, float* db, int64_t ld_db, int acc_b,
                  void* ws, hipStream_t s);
 int launch_axpy(const float* x, float* y, int64_t n, hipStream_t s);   // y += x
+// variational action encoder (action_vae.py:224-229, models/dists.py): params rows are [mean | logvar]
+int launch_gauss_sample(const float* params, int64_t ldp, const float* eps, float* z, int64_t ldz, int B, int D, hipStream_t s);
+int launch_gauss_sample_bwd(const float* params, int64_t ldp, const float* eps, const float* dz, int64_t ld_dz, float kl_scale, float* dparams,
+                            int64_t ld_dp, int B, int D, hipStream_t s);
 // alternate samplers (vita_meanflow.hip)
 int launch_step_times_affine(float* ts, int K, double scale, double offset, hipStream_t s);   // ts[k] = (float)(k/K*scale + offset)
 int launch_sde_update(const float* z, int64_t ldz, const float* v, const float* noise, float* out, int64_t ldo, int B, int D, float c_v,

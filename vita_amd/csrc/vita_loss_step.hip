@@ -131,6 +131,7 @@ struct CnnWs {
     float *d0 = nullptr, *d1 = nullptr; // gradient ping-pong, each max(B*Lout_0*C, B*C*Lf, B*L_i*C_i)
 };
 inline int conv_len(int T, int i) { return T >> i; }  // requires T % 2^NL == 0
+inline int proj_out(const vita_encoder_weights& w) { return w.variational ? 2 * w.D : w.D; }   // action_vae.py:213
 CnnWs carve_cnn(Carver& c, const vita_encoder_weights& w, size_t B, bool train) {
     CnnWs s;
     size_t dmax = 0;
@@ -162,19 +163,20 @@ int cnn_fwd(const vita_encoder_weights& w, const CnnWs& s, const float* actions,
         VITA_TRY(vita_nlc_ncl_f32(flat, s.flat, B, lf, cf, 1, st));   // x.view(B,-1) of the (B,C,L) tensor, :323
         flat = s.flat;
     }
-    return gemm_f32(lin(flat, cf * lf, w.proj_w, cf * lf, w.proj_b, z, ldz, B, w.D, cf * lf, VITA_ACT_NONE), st);
+    return gemm_f32(lin(flat, cf * lf, w.proj_w, cf * lf, w.proj_b, z, ldz, B, proj_out(w), cf * lf, VITA_ACT_NONE), st);
 }
 int cnn_bwd(const vita_encoder_weights& w, const vita_encoder_weights& g, const CnnWs& s, const float* actions, const float* dz,
             int64_t ld_dz, int B, float* cs_part, hipStream_t st) {
     const int lf = conv_len(w.T, w.NL);
     const int cf = w.NL ? w.C : w.A;
     const float* flat = lf > 1 ? s.flat : (w.NL ? s.out[w.NL - 1] : actions);
-    VITA_TRY(gemm_f32(wgrad(dz, ld_dz, flat, cf * lf, mut(g.proj_w), cf * lf, B, cf * lf, w.D), st));
-    VITA_TRY(vita_colsum_f32(dz, ld_dz, B, w.D, cs_part, mut(g.proj_b), 0, st));
+    const int PD = proj_out(w);
+    VITA_TRY(gemm_f32(wgrad(dz, ld_dz, flat, cf * lf, mut(g.proj_w), cf * lf, B, cf * lf, PD), st));
+    VITA_TRY(vita_colsum_f32(dz, ld_dz, B, PD, cs_part, mut(g.proj_b), 0, st));
     if (w.NL == 0) return VITA_OK;
     float* d_out = s.d0;
     float* d_alt = s.d1;
-    VITA_TRY(gemm_f32(dgrad(dz, ld_dz, w.proj_w, cf * lf, d_out, cf * lf, B, cf * lf, w.D), st));
+    VITA_TRY(gemm_f32(dgrad(dz, ld_dz, w.proj_w, cf * lf, d_out, cf * lf, B, cf * lf, PD), st));
     if (lf > 1) {
         VITA_TRY(vita_nlc_ncl_f32(d_out, d_alt, B, lf, cf, 0, st));
         float* t = d_out; d_out = d_alt; d_alt = t;
@@ -382,6 +384,8 @@ struct StepWs {
     float *sk, *consts, *loss_part, *cs_part;
     float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
     float *ut, *vt, *dut, *dxt, *dxa, *dxb;
+    float *params, *dparams, *kl_rows;  // variational encoder: [mean | logvar] rows (B, 2D), their gradient, per-row KL
+    void* stage; size_t stage_bytes;    // bf16 operand staging (cfg.gemm_bf16)
     float *nce_enc, *nce_flow, *dz0c;   // InfoNCE state (vita_contrastive.hip) and its d z0, added to dz0 at the end
     FlowTrainWs flow;
     StackWs dec;
@@ -395,8 +399,26 @@ int max_colsum_n(const vita_policy_weights& w) {
     auto up = [&](int v) { if (v > n) n = v; };
     up(w.flow.FF); up(w.flow.H); up(w.flow.D); up(4 * w.flow.TE);
     up(w.dec.HD); up(w.dec.OUT); up(w.dec.D);
-    up(w.enc.C * 4); up(w.enc.D);
+    up(w.enc.C * 4); up(w.enc.D * (w.enc.variational ? 2 : 1));
     return n;
+}
+
+// Upper bound of the bf16 staging one GEMM of the step needs: both operands as (rows, r8(k)) bf16.  The largest calls are
+// the stacked weight-gradient GEMMs (k = (1 + K) * B rows, operands of the two widest feature dims) and the forward /
+// input-gradient GEMMs over the same rows; a call that would not fit takes the fp32 kernels (gemm_f32_via_bf16).
+size_t bf16_stage_bytes(const vita_policy_weights& w, size_t B, size_t K) {
+    size_t rows = (1 + K) * B;
+    auto upr = [&](size_t v) { if (v > rows) rows = v; };
+    upr(2 * B);
+    upr(w.enc.kind == VITA_ENC_SIMPLE ? B * w.enc.T : B * (size_t)(w.enc.T / 2 > 0 ? w.enc.T / 2 : 1));
+    size_t d1 = 0, d2 = 0;   // the two widest feature dims any GEMM pairs
+    auto upd = [&](size_t v) { if (v > d1) { d2 = d1; d1 = v; } else if (v > d2) { d2 = v; } };
+    upd(w.flow.FF); upd(w.flow.H); upd(w.flow.D); upd(w.dec.HD); upd(w.dec.HD); upd(w.dec.OUT); upd(w.O);
+    upd((size_t)w.enc.C * (w.enc.kind == VITA_ENC_SIMPLE ? 4 : 5)); upd(w.enc.C); upd((size_t)w.enc.D * (w.enc.variational ? 2 : 1));
+    const size_t r8rows = (rows + 7) & ~size_t(7), a = (d1 + 7) & ~size_t(7), b = (d2 + 7) & ~size_t(7);
+    const size_t by_rows = (a + b) * r8rows * 2;                 // wgrad: (d1, rows) + (d2, rows); fwd/dgrad: (rows, d) + (d, d')
+    const size_t by_w = (r8rows * a + a * a) * 2;
+    return ((by_rows > by_w ? by_rows : by_w) + 1023) & ~size_t(255);
 }
 
 StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config& cfg, size_t B, bool train) {
@@ -425,6 +447,15 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     if (nce_e) s.nce_enc = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
     if (nce_f) s.nce_flow = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
     if (train && (nce_e || nce_f)) s.dz0c = c.take(B * D);
+    if (w.enc.variational) {
+        s.params = c.take(B * 2 * D);
+        s.kl_rows = c.take(B);
+        if (train) s.dparams = c.take(B * 2 * D);
+    }
+    if (cfg.gemm_bf16) {
+        s.stage_bytes = bf16_stage_bytes(w, B, K);
+        s.stage = c.take(s.stage_bytes / sizeof(float));
+    }
     s.flow = carve_flow_train(c, w.flow, B, K, train);
     s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
@@ -437,6 +468,8 @@ int check_enc_weights(const vita_encoder_weights* w, const char* who) {
     VITA_REQUIRE(w->kind == VITA_ENC_CNN || w->kind == VITA_ENC_SIMPLE, "%s: unknown encoder kind %d", who, w->kind);
     VITA_REQUIRE(w->A > 0 && w->T > 0 && w->C > 0 && w->D > 0 && w->NL >= 0 && w->NL <= VITA_MAX_LAYERS, "%s: bad encoder dims", who);
     VITA_REQUIRE(w->proj_w && w->proj_b, "%s: null encoder projection", who);
+    VITA_REQUIRE(w->variational == 0 || w->variational == 1, "%s: encoder `variational` must be 0 or 1", who);
+    VITA_REQUIRE(!w->variational || w->kind == VITA_ENC_CNN, "%s: the variational encoder is the CNN one (action_vae.py:400-418)", who);
     if (w->kind == VITA_ENC_CNN) {
         VITA_REQUIRE((w->T >> w->NL) >= 1 && (w->T % (1 << w->NL)) == 0,
                      "%s: cnn encoder needs pred_horizon %% 2^num_layers == 0 (T=%d, NL=%d; action_ae.py:311)", who, w->T, w->NL);
@@ -476,7 +509,7 @@ int zero_encoder_grads(const vita_encoder_weights& g, hipStream_t st) {
         for (int i = 0; i < g.NL; ++i) {
             VITA_TRY(z(g.w1[i], (size_t)g.C * (i == 0 ? g.A : g.C) * 5)); VITA_TRY(z(g.b1[i], (size_t)g.C));
         }
-        VITA_TRY(z(g.proj_w, (size_t)g.D * g.C * (g.T >> g.NL))); VITA_TRY(z(g.proj_b, (size_t)g.D));
+        VITA_TRY(z(g.proj_w, (size_t)proj_out(g) * (g.NL ? g.C : g.A) * (g.T >> g.NL))); VITA_TRY(z(g.proj_b, (size_t)proj_out(g)));
     }
     return VITA_OK;
 }
@@ -504,7 +537,7 @@ size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vit
 
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t, const int64_t* pair_i,
-                          const int64_t* pair_j, int32_t B, float* losses, float* d_obs_features, int64_t ld_dobs,
+                          const int64_t* pair_j, const float* enc_noise, int32_t B, float* losses, float* d_obs_features, int64_t ld_dobs,
                           void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream) {
     const char* who = "vita_compute_loss_f32";
     VITA_TRY(check_policy(w, who));
@@ -515,13 +548,16 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     VITA_REQUIRE(cfg->enc_contrastive_weight >= 0.f && cfg->flow_contrastive_weight >= 0.f && cfg->temperature >= 0.f,
                  "%s: negative contrastive weight / temperature", who);
     VITA_REQUIRE(B >= 1, "%s: B must be >= 1 (the mean over an empty batch is undefined)", who);
+    VITA_REQUIRE(cfg->kl_weight >= 0.f && cfg->gemm_bf16 >= 0 && cfg->gemm_bf16 <= 2, "%s: bad kl_weight / gemm_bf16", who);
+    VITA_REQUIRE(enc_noise == nullptr || w->enc.variational, "%s: enc_noise is the variational encoder's draw; this encoder is not variational", who);
     VITA_REQUIRE(obs_features && actions && t && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/losses", who);
     VITA_REQUIRE(d_obs_features == nullptr || (grads != nullptr && ld_dobs >= w->O), "%s: d_obs_features needs grads and ld_dobs >= O", who);
     if (grads) {
         VITA_REQUIRE(grads->O == w->O && grads->flow.D == w->flow.D && grads->flow.H == w->flow.H && grads->flow.FF == w->flow.FF &&
                          grads->flow.L == w->flow.L && grads->flow.TE == w->flow.TE && grads->dec.HD == w->dec.HD &&
                          grads->dec.NL == w->dec.NL && grads->dec.OUT == w->dec.OUT && grads->enc.kind == w->enc.kind &&
-                         grads->enc.C == w->enc.C && grads->enc.NL == w->enc.NL && grads->enc.A == w->enc.A && grads->enc.T == w->enc.T,
+                         grads->enc.C == w->enc.C && grads->enc.NL == w->enc.NL && grads->enc.A == w->enc.A && grads->enc.T == w->enc.T &&
+                         grads->enc.variational == w->enc.variational,
                      "%s: the gradient descriptor's dims differ from the weights'", who);
     }
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_compute_loss_workspace_bytes(w, cfg, B), who));
@@ -544,6 +580,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     float* z1 = s.ZZ + (size_t)B * D;
     FlowCtx fc{&w->flow, s.flow, B, K, 1 + K, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
+    Bf16Scope bfscope(s.stage, s.stage_bytes, cfg->gemm_bf16);
+    const bool vae = w->enc.variational != 0;
+    const bool do_kl = vae && !fe && !(fe && fd) && cfg->kl_weight > 0.f;                                               // :142-146
 
     // loss weights as device scalars (seeds of the backward pass) ; zero the outputs
     const float seeds[6] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight, cfg->enc_contrastive_weight,
@@ -553,7 +592,14 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
 
     // ---- forward ------------------------------------------------------------------------------
     VITA_TRY(gemm_f32(lin(obs_features, ldobs, w->obs_w, w->O, w->obs_b, s.z0, D, B, D, w->O, VITA_ACT_NONE), st));   // :114
-    VITA_TRY(encoder_fwd(w->enc, s, actions, z1, D, B, st));                                                          // :123
+    if (vae) {                                                                                                        // :121
+        VITA_TRY(encoder_fwd(w->enc, s, actions, s.params, 2 * D, B, st));
+        VITA_TRY(launch_gauss_sample(s.params, 2 * D, enc_noise, z1, D, B, D, st));
+        // deterministic posterior: kl() is zeros (dists.py:25-26) and the loss entry stays 0
+        if (do_kl && enc_noise) VITA_TRY(vita_gaussian_kl_fwd_f32(s.params, 2 * D, s.params + D, 2 * D, B, D, s.kl_rows, losses + VITA_LOSS_ACTION_KL, st));
+    } else {
+        VITA_TRY(encoder_fwd(w->enc, s, actions, z1, D, B, st));                                                      // :123
+    }
     // time path for the B per-row timesteps of the flow-matching draw and the K Euler steps
     VITA_CHECK_HIP(hipMemcpyAsync(s.flow.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     if (K > 0) VITA_TRY(launch_step_times(s.flow.ts + B, K, st));
@@ -587,10 +633,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         if (dec_pred) VITA_TRY(recon(s.dec.out, actions, n_rec, s.loss_part, losses + VITA_LOSS_FLOW_RECON, st));
         if (dec_enc) VITA_TRY(recon(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.loss_part, losses + VITA_LOSS_ENC_RECON, st));
     }
-    const float wsum[7] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
+    const float wsum[8] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
                            dec_enc ? cfg->enc_recon_weight : 0.f, nce_enc ? cfg->enc_contrastive_weight : 0.f,
-                           nce_flow ? cfg->flow_contrastive_weight : 0.f};
-    VITA_TRY(launch_weighted_sum(losses, wsum, 7, losses + VITA_LOSS_TOTAL, st));
+                           nce_flow ? cfg->flow_contrastive_weight : 0.f, do_kl ? cfg->kl_weight : 0.f};
+    VITA_TRY(launch_weighted_sum(losses, wsum, 8, losses + VITA_LOSS_TOTAL, st));
     if (!train) return VITA_OK;
 
     // ---- backward -----------------------------------------------------------------------------
@@ -658,6 +704,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     } else if (w->enc.kind == VITA_ENC_SIMPLE) {
         VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
                            w->enc.C, nullptr, 0, s.cs_part, st));
+    } else if (vae) {
+        const float ks = (do_kl && enc_noise) ? cfg->kl_weight / (float)B : 0.f;
+        VITA_TRY(launch_gauss_sample_bwd(s.params, 2 * D, enc_noise, dz1, D, ks, s.dparams, 2 * D, B, D, st));
+        VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, s.dparams, 2 * D, B, s.cs_part, st));
     } else {
         VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, dz1, D, B, s.cs_part, st));
     }
@@ -684,7 +734,7 @@ int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* 
     VITA_TRY(check_enc_weights(w, who));
     VITA_REQUIRE(B >= 0, "%s: B < 0", who);
     if (B == 0) return VITA_OK;
-    VITA_REQUIRE(actions && latents && ldl >= w->D, "%s: bad actions/latents", who);
+    VITA_REQUIRE(actions && latents && ldl >= proj_out(*w), "%s: bad actions/latents (a variational encoder writes 2*D columns)", who);
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_action_encoder_workspace_bytes(w, B), who));
     Carver c(workspace);
     StepWs s{};

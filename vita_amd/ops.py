@@ -748,7 +748,12 @@ def _fill_enc(w, g, prefix: str, sd, pred_horizon: int, latent_dim: int) -> None
         for i in range(n):
             w.w1[i] = g(f"{prefix}encoder.{2 * i}.weight").data_ptr()
             w.b1[i] = g(f"{prefix}encoder.{2 * i}.bias").data_ptr()
-        w.proj_w, w.proj_b = g(prefix + "latent_proj.weight").data_ptr(), g(prefix + "latent_proj.bias").data_ptr()
+        pw_ = g(prefix + "latent_proj.weight")
+        w.proj_w, w.proj_b = pw_.data_ptr(), g(prefix + "latent_proj.bias").data_ptr()
+        if pw_.shape[0] == 2 * latent_dim:         # variational CNNActionEncoder, action_vae.py:213
+            w.variational = 1
+        elif pw_.shape[0] != latent_dim:
+            raise L.VitaHipError(f"action_encoder.latent_proj has {pw_.shape[0]} outputs; expected latent_dim={latent_dim} or twice that")
     else:                                          # SimpleActionEncoder, :111-170
         w.kind = L.ENC_SIMPLE
         pw = g(prefix + "input_proj.weight")
@@ -789,7 +794,7 @@ class PolicyHandle:
 def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
                 enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, enc_contrastive_weight: float = 0.0,
                 flow_contrastive_weight: float = 0.0, temperature: float = 0.07, freeze_encoder: bool = False,
-                freeze_decoder: bool = False) -> "L.LossConfig":
+                freeze_decoder: bool = False, kl_weight: float = 0.0, gemm_bf16: int = 0) -> "L.LossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")   # vita_policy.py:71
     c = L.LossConfig()
@@ -797,11 +802,13 @@ def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool
     c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
     c.enc_contrastive_weight, c.flow_contrastive_weight, c.temperature = enc_contrastive_weight, flow_contrastive_weight, temperature
     c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
+    c.kl_weight, c.gemm_bf16 = float(kl_weight), int(gemm_bf16)
     return c
 
 
 def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, *, grads: Optional[PolicyHandle] = None,
-                 pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None):
+                 pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None,
+                 enc_noise: Optional[Tensor] = None):
     """VitaPolicy.compute_loss (+ backward when `grads` is given), vita_policy.py:112-189.  Returns
     (losses (8,) device tensor indexed as _lib.LOSS_NAMES, d_obs_features or None).  No host sync."""
     lib = L.load()
@@ -814,6 +821,10 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
                              f"do not match O={pw.O}, T={pw.T}, A={pw.A}")
     dev = obs_features.device
     pair_i, pair_j = _idx(pair_i, dev), _idx(pair_j, dev)
+    if enc_noise is not None:
+        enc_noise = _f32(enc_noise, "compute_loss: enc_noise").contiguous()
+        if tuple(enc_noise.shape) != (B, pw.D):
+            raise L.VitaHipError(f"compute_loss: enc_noise {tuple(enc_noise.shape)} must be (B, D) = ({B}, {pw.D})")
     if losses is None:
         losses = torch.empty(L.LOSS_COUNT, dtype=torch.float32, device=dev)
     dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
@@ -832,21 +843,24 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
     L.check(lib.vita_compute_loss_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
                                       obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(),
                                       pair_i.data_ptr() if pair_i is not None else None,
-                                      pair_j.data_ptr() if pair_j is not None else None, B, losses.data_ptr(),
+                                      pair_j.data_ptr() if pair_j is not None else None,
+                                      enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
                                       dobs.data_ptr() if dobs is not None else None, pw.O, ev, ws.data_ptr(), ws.numel(),
                                       _stream(obs_features)), "vita_compute_loss_f32")
     return losses, dobs
 
 
 def action_encoder_forward(pw: PolicyHandle, actions: Tensor) -> Tensor:
-    """CNNActionEncoder.forward / SimpleActionEncoder.forward (action_ae.py:318-327, 161-170)."""
+    """CNNActionEncoder.forward / SimpleActionEncoder.forward (action_ae.py:318-327, 161-170).  For the variational
+    encoder the result is the posterior's parameter rows (B, 2D) = [mean | logvar] (action_vae.py:224)."""
     lib = L.load()
     actions = _f32(actions, "action_encoder_forward").contiguous()
     B = actions.shape[0]
-    z = torch.empty((B, pw.D), dtype=torch.float32, device=actions.device)
+    width = pw.D * (2 if pw.w.enc.variational else 1)
+    z = torch.empty((B, width), dtype=torch.float32, device=actions.device)
     nbytes = lib.vita_action_encoder_workspace_bytes(C.byref(pw.w.enc), B)
     ws = workspace(actions.device, nbytes)
-    L.check(lib.vita_action_encoder_forward_f32(C.byref(pw.w.enc), actions.data_ptr(), z.data_ptr(), pw.D, B, ws.data_ptr(),
+    L.check(lib.vita_action_encoder_forward_f32(C.byref(pw.w.enc), actions.data_ptr(), z.data_ptr(), width, B, ws.data_ptr(),
                                                 ws.numel(), _stream(actions)), "vita_action_encoder_forward_f32")
     return z
 

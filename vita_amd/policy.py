@@ -142,8 +142,14 @@ def make_mean_flow_net(D, H, L_, mlp_ratio) -> nn.Module:
     return net
 
 
-def make_action_encoder(kind, T, A, D, hidden, num_layers) -> nn.Module:
+def make_action_encoder(kind, T, A, D, hidden, num_layers, variational: bool = False) -> nn.Module:
+    """get_autoencoder (action_ae.py:330-374) / get_variational_autoencoder (action_vae.py:390-420): the variational CNN
+    encoder differs only in latent_proj's width (2 * latent_dim: [mean | logvar], action_vae.py:213)."""
     enc = _Holder()
+    if variational and kind != "cnn":
+        if kind == "transformer":
+            raise NotImplementedError("encoder_type 'transformer' is outside this build's hot path (SURVEY.md section 2 #3)")
+        raise ValueError(f"Unknown encoder type: {kind}")   # action_vae.py:420
     if kind == "cnn":                                   # action_ae.py:282-316
         if T // (2 ** num_layers) < 1 or T % (2 ** num_layers):
             raise ValueError(f"cnn encoder: pred_horizon {T} must be a multiple of 2^num_layers ({num_layers})")
@@ -152,7 +158,7 @@ def make_action_encoder(kind, T, A, D, hidden, num_layers) -> nn.Module:
             mods += [nn.Conv1d(c, hidden, kernel_size=5, stride=2, padding=2), nn.ReLU()]
             c = hidden
         enc.encoder = nn.Sequential(*mods)
-        enc.latent_proj = nn.Linear(hidden * (T // (2 ** num_layers)), D)
+        enc.latent_proj = nn.Linear(hidden * (T // (2 ** num_layers)), 2 * D if variational else D)
         _orthogonal(enc)
     elif kind == "simple":                              # action_ae.py:111-159
         ald = D // T
@@ -198,13 +204,13 @@ class _FusedLoss(torch.autograd.Function):
     fused forward+backward; backward hands the staged gradients to autograd (scaled by the incoming grad)."""
 
     @staticmethod
-    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, *params):
+    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, enc_noise, *params):
         pw, gw, gsd = policy._train_handles(stage=True)
         frozen = policy.frozen_prefixes()
         staged = [None if k.startswith(frozen) else gsd[k] for k, _ in policy.hot_path_named_parameters()]
         need_dobs = obs_features.requires_grad
         losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
-                                        need_dobs=need_dobs)
+                                        need_dobs=need_dobs, enc_noise=enc_noise)
         ctx.staged, ctx.dobs = staged, dobs
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
@@ -213,7 +219,7 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, gout, _):
         grads = tuple((g * gout if g is not None else None) for g in ctx.staged)
         dobs = ctx.dobs * gout if ctx.dobs is not None else None
-        return (None, dobs, None, None, None, None) + grads
+        return (None, dobs, None, None, None, None, None) + grads
 
 
 class VitaPolicy(nn.Module):
@@ -254,13 +260,12 @@ class VitaPolicy(nn.Module):
             raise ValueError(f"Unsupported recon_loss_type: {ae.recon_loss_type}. Use 'l1' or 'l2'.")   # :71
         self.enc_contrastive_weight = pol.vita.enc_contrastive_weight
         self.flow_contrastive_weight = pol.vita.flow_contrastive_weight
-        unsupported = []
-        if self.use_action_vae: unsupported.append("action_ae.use_variational")
-        if unsupported:
-            raise NotImplementedError("non-default branches outside this build's fused training path: " + ", ".join(unsupported))
+        if self.use_action_vae and net.decoder_type == "cnn":
+            raise NotImplementedError("action_ae.use_variational with decoder_type 'cnn' (CNNActionDecoder, action_vae.py:232-298) "
+                                      "is outside this build's fused training path; decoder_type 'simple' is built")
         self.obs_encoder = nn.Linear(self.obs_dim, self.latent_dim)                                      # :77
         self.action_encoder = make_action_encoder(net.encoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
-                                                  net.enc_hidden_dim, net.num_layers)                   # :101-110
+                                                  net.enc_hidden_dim, net.num_layers, bool(self.use_action_vae))   # :101-110
         self.action_decoder = make_action_decoder(net.decoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
                                                   net.dec_hidden_dim, net.num_layers)
         fn = pol.flow_net
@@ -277,6 +282,12 @@ class VitaPolicy(nn.Module):
             self.flow_net = make_mean_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)
         else:
             self.flow_net = make_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)  # :90-97
+        # GEMM operand type: "f32" (default: the reference's strict-fp32 numerics), "bf16" (bf16 MFMA operands, fp32
+        # accumulate: inference always, training for the GEMMs large enough to gain, vita_loss_config.gemm_bf16 = 1) or
+        # "bf16_all" (training: every GEMM).  Stated tolerances in tests/test_gpu_bf16*.py.  Not a reference key.
+        self.gemm_dtype = str(pol.get("gemm_dtype", "f32"))
+        if self.gemm_dtype not in ("f32", "bf16", "bf16_all"):
+            raise ValueError(f"policy.gemm_dtype must be 'f32', 'bf16' or 'bf16_all', got {self.gemm_dtype!r}")
         self._loss_cfg = ops.loss_config(num_steps=self.num_sampling_steps, recon=ae.recon_loss_type,
                                          decode_flow_latents=bool(pol.vita.decode_flow_latents),
                                          consistency_weight=float(pol.vita.consistency_weight),
@@ -285,12 +296,9 @@ class VitaPolicy(nn.Module):
                                          enc_contrastive_weight=float(self.enc_contrastive_weight),
                                          flow_contrastive_weight=float(self.flow_contrastive_weight),
                                          freeze_encoder=bool(self.freeze_action_encoder),
-                                         freeze_decoder=bool(self.freeze_action_decoder))
-        # GEMM operand type for INFERENCE: "f32" (default: the reference's strict-fp32 numerics) or "bf16" (bf16 MFMA operands,
-        # fp32 accumulate; stated tolerance 2e-2 on the actions).  Not a reference key: policy.gemm_dtype.
-        self.gemm_dtype = str(pol.get("gemm_dtype", "f32"))
-        if self.gemm_dtype not in ("f32", "bf16"):
-            raise ValueError(f"policy.gemm_dtype must be 'f32' or 'bf16', got {self.gemm_dtype!r}")
+                                         freeze_decoder=bool(self.freeze_action_decoder),
+                                         kl_weight=float(self.action_kl_weight) if self.use_action_vae else 0.0,
+                                         gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype])
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -419,8 +427,14 @@ class VitaPolicy(nn.Module):
         return self.compute_loss(batch)
 
     # -- the hot path -----------------------------------------------------------------------------------
-    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None):
-        """t ~ U(0,1) and the OT pairing, on the host as in the reference (flow_matchers.py:34 -> torchcfm)."""
+    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None, enc_noise=None):
+        """The host-side random draws of one compute_loss call, in the reference's order: the variational posterior's
+        eps (torch.randn_like on the device, dists.py:20; training mode only, vita_policy.py:121), then t ~ U(0,1) and the
+        OT pairing (flow_matchers.py:34 -> torchcfm).  Returns (t, pair_i, pair_j, enc_noise)."""
+        if self.use_action_vae and self.training and enc_noise is None:
+            enc_noise = torch.randn(batch_size, self.latent_dim, device=dev)
+        if not (self.use_action_vae and self.training):
+            enc_noise = None        # deterministic posterior: z = mean, KL = 0
         if t is None:
             t = torch.rand(batch_size).to(dev)
         if self.FM.pairing == "exact" and pair_i is None and pair_j is None:
@@ -428,11 +442,14 @@ class VitaPolicy(nn.Module):
             _, _, pw = self._infer_handles()
             z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
             z1 = ops.action_encoder_forward(pw, actions)
+            if self.use_action_vae:     # (B, 2D) rows [mean | logvar]; the sample feeds only the host-side OT plan here
+                mean, logvar = z1[:, :self.latent_dim], z1[:, self.latent_dim:]
+                z1 = mean if enc_noise is None else mean + torch.exp(0.5 * logvar) * enc_noise
             from .flow import exact_ot_pairing
             pair_i, pair_j = exact_ot_pairing(z0, z1)
-        return t, pair_i, pair_j
+        return t, pair_i, pair_j, enc_noise
 
-    def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None):
+    def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None, enc_noise=None):
         """Native training entry (no autograd): normalised batch -> losses (device float[8], _lib.LOSS_NAMES order), with
         d loss / d parameter written into the parameters' .grad buffers.  No host synchronisation."""
         if self.inference_only:
@@ -440,16 +457,17 @@ class VitaPolicy(nn.Module):
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
-        t, pair_i, pair_j = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions)
+        t, pair_i, pair_j, enc_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions,
+                                                  enc_noise)
         pw, gw, gsd = self._train_handles()
         if self._flat_grad is None:
             for (k, p) in self.hot_path_named_parameters():
                 p.grad = gsd[k]
         out, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
-                                  grad_ready_events=grad_ready_events, losses=losses)
+                                  grad_ready_events=grad_ready_events, losses=losses, enc_noise=enc_noise)
         return out
 
-    def compute_loss(self, batch, *, t=None, pair_i=None, pair_j=None):
+    def compute_loss(self, batch, *, t=None, pair_i=None, pair_j=None, enc_noise=None):
         """vita_policy.py:112-189.  Returns (loss, metrics) with the reference's metric keys; `loss` supports
         .backward() (drop-in for policy_trainer.py:79-82).  One device->host copy for all metrics (the reference
         does one .item() per metric)."""
@@ -458,13 +476,14 @@ class VitaPolicy(nn.Module):
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
-        t, pair_i, pair_j = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions)
+        t, pair_i, pair_j, enc_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions,
+                                                  enc_noise)
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
             params = [p for _, p in self.hot_path_named_parameters()]
-            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, *params)
+            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, *params)
         else:
             _, _, pw = self._infer_handles()
-            losses, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j)
+            losses, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise)
             loss = losses[0]
         vals = losses.detach().cpu().tolist()
         metrics = {"loss": vals[1], "flow_loss": vals[1]}   # FM.compute_loss's own 'loss' entry is the flow loss (flow_matchers.py:39)
@@ -472,6 +491,8 @@ class VitaPolicy(nn.Module):
         if self.enc_contrastive_weight > 0:
             metrics["enc_contrastive_loss"] = vals[5]
         fe, fd = self.freeze_action_encoder, self.freeze_action_decoder
+        if not fe and self.use_action_vae and self.action_kl_weight > 0 and not (fe and fd):      # :142-150
+            metrics["action_kl_loss"] = vals[7]
         if cfgv.decode_flow_latents and not fe and not fd:
             if cfgv.consistency_weight > 0:
                 metrics["consistency_loss"] = vals[2]
@@ -492,7 +513,7 @@ class VitaPolicy(nn.Module):
             z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
             z = self.FM.sample(fw, shape=tuple(z0.shape), device=z0.device, start=z0, num_steps=self.num_sampling_steps)
             return ops.decoder_forward(dw, z).view(-1, self.pred_horizon, self.action_dim)
-        if self.gemm_dtype == "bf16":
+        if self.gemm_dtype != "f32":
             out = ops.generate_actions_bf16(self.obs_encoder.bias.data, fw, dw, self._bf16_weights(), obs_features,
                                             self.num_sampling_steps)
         else:
