@@ -118,7 +118,7 @@ def test_policy_gemm_dtype_bf16_trains(dev):
     tr = PolicyTrainer(cfg, pol, dev, num_training_steps=10)
     g = torch.Generator().manual_seed(2)
     batch = make_batch(cfg, 16, g)
-    t = torch.rand(16, generator=g)
+    t = torch.rand(16, generator=g).to(dev)
     first = None
     for _ in range(8):
         tr.train_step(batch, t=t)
