@@ -204,6 +204,19 @@ int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, c
 int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float* t, const int64_t* pair_i, const int64_t* pair_j,
                                  float* dx0, float* dx1, int32_t B, int32_t D, int32_t accumulate, vita_stream_t stream);
 
+/* The same for every Gaussian-path matcher of torchcfm==1.0.5 that the reference registers (flow_matchers.py:82-99,137-145;
+ * RESTATED from the published source, UNPINNED — torchcfm is absent from the image and no reference fixture covers it):
+ *   VITA_FM_CONDITIONAL ('conditional', 'exact'): xt = t*x1 + (1-t)*x0 + sigma*eps,               ut = x1 - x0
+ *   VITA_FM_TARGET      ('target'):               xt = t*x1 + st*eps, st = 1 - (1-sigma)*t,        ut = (x1 - (1-sigma)*xt) / st
+ *   VITA_FM_SCHRODINGER ('schrodinger', sigma>0): xt = t*x1 + (1-t)*x0 + sigma*sqrt(t(1-t))*eps,   ut = (1-2t)/(2t(1-t)+1e-8)*(xt - mu) + x1 - x0
+ * eps (B,D): the randn_like(x0) draw of sample_location_and_conditional_flow, indexed by output row; may be NULL only for
+ * VITA_FM_CONDITIONAL with sigma == 0.  The backward follows the accumulate / pairing rules of vita_cfm_interpolate_bwd_f32. */
+enum { VITA_FM_CONDITIONAL = 0, VITA_FM_TARGET = 1, VITA_FM_SCHRODINGER = 2 };
+int vita_fm_interpolate_f32(int32_t kind, double sigma, const float* x0, const float* x1, const float* t, const float* eps,
+                            const int64_t* pair_i, const int64_t* pair_j, float* xt, float* ut, int32_t B, int32_t D, vita_stream_t stream);
+int vita_fm_interpolate_bwd_f32(int32_t kind, double sigma, const float* dxt, const float* dut, const float* t, const int64_t* pair_i,
+                                const int64_t* pair_j, float* dx0, float* dx1, int32_t B, int32_t D, int32_t accumulate, vita_stream_t stream);
+
 /* (x - mean) / (std + 1e-8) and x*std + mean for x viewed as (rows, C, inner) with per-C statistics:
  * Normalize.forward / Unnormalize.forward, normalize.py:38-46,62-70.  inner = 1 for state / action vectors
  * (stats of shape (C)); inner = H*W for images with stats of shape (C,1,1). */
@@ -312,6 +325,8 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
                                       operands (fp32 -> bf16 staged per call, fp32 accumulate / epilogue / master weights /
                                       gradients); 2: every GEMM does.  NOT bit-comparable with fp32: stated tolerance in
                                       tests/test_gpu_bf16_train.py (BASELINE configs[2]) */
+    int32_t fm_kind;               /* VITA_FM_*: flow_matcher.name conditional / exact (0), target (1), schrodinger (2) */
+    float fm_sigma;                /* flow_matcher.sigma (vita.yaml:24: 0.0); > 0 or kinds 1 / 2 need `fm_noise` */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,
@@ -325,6 +340,8 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
  *   pred = Euler_K(z0);  L_c = mse(pred, z1);  L_fr = recon(dec(pred), actions);  L_er = recon(dec(z1), actions)
  *   loss = L_flow + cw*L_c + fw*L_fr + ew*L_er
  * `t` (B) and the OT pairing (NULL = identity) are inputs: the reference draws them on the host (torchcfm / POT).
+ * fm_noise: (B, D) standard-normal draw of the matcher (randn_like(x0) in torchcfm's sample_location_and_conditional_flow);
+ *   required unless cfg->fm_kind == VITA_FM_CONDITIONAL and cfg->fm_sigma == 0 (then it may be NULL).
  * enc_noise: variational encoder only (vita_encoder_weights.variational): the (B, D) standard-normal draw of
  *   DiagonalGaussianDistribution.sample (dists.py:20-21): z1 = mean + exp(0.5*logvar) * enc_noise, and with kl_weight > 0
  *   and an unfrozen encoder loss += kl_weight * mean_b(0.5 * sum_c(mean^2 + var - 1 - logvar)) (:146-150).  NULL = the
@@ -340,7 +357,8 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
 size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B);
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t,
-                          const int64_t* pair_i, const int64_t* pair_j, const float* enc_noise, int32_t B, float* losses,
+                          const int64_t* pair_i, const int64_t* pair_j, const float* fm_noise, const float* enc_noise,
+                          int32_t B, float* losses,
                           float* d_obs_features, int64_t ld_dobs,
                           void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream);
 

@@ -144,21 +144,42 @@ def euler_sample(sd: SD, x0: Tensor, num_steps: int, return_traces: bool = False
 
 
 def cfm_sample_location_and_conditional_flow(x0: Tensor, x1: Tensor, t: Tensor,
-                                             sigma: float = 0.0, eps: Tensor | None = None):
-    """torchcfm==1.0.5 ConditionalFlowMatcher.sample_location_and_conditional_flow
-    (RESTATED, UNPINNED; called at flow_matchers.py:34): mu_t = t*x1 + (1-t)*x0,
-    xt = mu_t + sigma*eps, ut = x1 - x0.  `t` (B,) and `eps` are explicit inputs here (the
+                                             sigma: float = 0.0, eps: Tensor | None = None, kind: str = "conditional"):
+    """torchcfm==1.0.5 sample_location_and_conditional_flow of ConditionalFlowMatcher and its two
+    Gaussian-path subclasses the reference registers (RESTATED, UNPINNED; called at
+    flow_matchers.py:34; classes built at :82-99):
+      conditional / exact: mu_t = t*x1 + (1-t)*x0, sigma_t = sigma,                 ut = x1 - x0
+      target:              mu_t = t*x1,            sigma_t = 1 - (1-sigma)*t,       ut = (x1 - (1-sigma)*xt) / (1 - (1-sigma)*t)
+      schrodinger:         mu_t as conditional,    sigma_t = sigma*sqrt(t*(1-t)),
+                           ut = (1-2t) / (2*t*(1-t) + 1e-8) * (xt - mu_t) + x1 - x0
+    xt = mu_t + sigma_t*eps.  `t` (B,) and `eps` (= randn_like(x0)) are explicit inputs here (the
     reference draws them from the global torch RNG)."""
     tt = t.reshape(-1, *([1] * (x0.dim() - 1)))
-    mu_t = tt * x1 + (1 - tt) * x0
-    xt = mu_t if (sigma == 0.0 or eps is None) else mu_t + sigma * eps
-    ut = x1 - x0
+    if kind in ("conditional", "exact"):
+        mu_t = tt * x1 + (1 - tt) * x0
+        xt = mu_t if (sigma == 0.0 or eps is None) else mu_t + sigma * eps
+        ut = x1 - x0
+    elif kind == "target":
+        mu_t = tt * x1
+        sigma_t = 1 - (1 - sigma) * tt
+        xt = mu_t + sigma_t * eps
+        ut = (x1 - (1 - sigma) * xt) / (1 - (1 - sigma) * tt)
+    elif kind == "schrodinger":
+        if sigma <= 0:
+            raise ValueError(f"Sigma must be strictly positive, got {sigma}.")
+        mu_t = tt * x1 + (1 - tt) * x0
+        sigma_t = sigma * torch.sqrt(tt * (1 - tt))
+        xt = mu_t + sigma_t * eps
+        ratio = (1 - 2 * tt) / (2 * tt * (1 - tt) + 1e-8)
+        ut = ratio * (xt - mu_t) + x1 - x0
+    else:
+        raise ValueError(f"unknown matcher kind {kind}")
     return t, xt, ut
 
 
 def fm_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, pair_i: Tensor | None = None,
             pair_j: Tensor | None = None, sigma: float = 0.0, eps: Tensor | None = None,
-            prefix: str = "flow_net.") -> Tensor:
+            prefix: str = "flow_net.", kind: str = "conditional") -> Tensor:
     """TorchFlowMatcher.compute_loss, flow_matchers.py:19-39.  The exact-OT matcher re-pairs
     (x0[i], x1[j]) from a minibatch OT plan before the CFM draw (torchcfm OTPlanSampler,
     UNPINNED): the pairing is an explicit input (pair_i, pair_j); None = identity pairing,
@@ -168,7 +189,7 @@ def fm_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, pair_i: Tensor | N
         x0 = x0[pair_i]
     if pair_j is not None:
         x1 = x1[pair_j]
-    _, xt, ut = cfm_sample_location_and_conditional_flow(x0, x1, t, sigma, eps)
+    _, xt, ut = cfm_sample_location_and_conditional_flow(x0, x1, t, sigma, eps, kind)
     vt = flow_net_forward(sd, xt, t, prefix)
     return torch.mean((vt - ut) ** 2)                      # :36
 
@@ -380,7 +401,8 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
                  enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
                  decode_flow_latents: bool = True, sigma: float = 0.0,
                  freeze_encoder: bool = False, freeze_decoder: bool = False,
-                 kl_weight: float = 0.0, enc_noise: Tensor | None = None):
+                 kl_weight: float = 0.0, enc_noise: Tensor | None = None,
+                 fm_kind: str = "conditional", fm_noise: Tensor | None = None):
     """VitaPolicy.compute_loss, vita_policy.py:112-189, from observer features on, with the
     freeze flags of :119,142-143,153,174,183.  A state dict whose action_encoder.latent_proj is
     2*latent_dim wide is the variational autoencoder (use_variational, :120-121,146-150):
@@ -399,7 +421,7 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
         action_latents = action_encode(sd, gt_actions)                          # :123
     if freeze_encoder:                                                          # :119 torch.no_grad()
         action_latents = action_latents.detach()
-    flow_loss = fm_loss(sd, obs_latents, action_latents, t, pair_i, pair_j, sigma)  # :126-130
+    flow_loss = fm_loss(sd, obs_latents, action_latents, t, pair_i, pair_j, sigma, fm_noise, kind=fm_kind)  # :126-130
     loss = flow_loss
     m["flow_loss"] = flow_loss
     if enc_contrastive_weight > 0:                                              # :134-139

@@ -111,10 +111,14 @@ def test_flow_matcher_table():
     assert set(FLOW_MATCHER_CLASSES) == {"conditional", "target", "schrodinger", "exact", "mean", "improved_mean", "consistency"}
     assert get_flow_matcher("exact", sigma=0.0, num_sampling_steps=6).pairing == "exact"
     assert get_flow_matcher("conditional").num_sampling_steps == 6
-    with pytest.raises(NotImplementedError):
-        get_flow_matcher("target")
-    with pytest.raises(NotImplementedError):
-        get_flow_matcher("exact", sigma=0.1)
+    from vita_amd import _lib as L
+    tg = get_flow_matcher("target", sigma=0.0, num_sampling_steps=6)                        # flow_matchers.py:87-89
+    assert tg.kind == L.FM_TARGET and tg.pairing == "identity" and tg.needs_noise
+    assert get_flow_matcher("exact", sigma=0.1).needs_noise and not get_flow_matcher("exact", sigma=0.0).needs_noise
+    sb = get_flow_matcher("schrodinger", sigma=0.5)                                         # :92-94
+    assert sb.kind == L.FM_SCHRODINGER and sb.pairing == "exact" and sb.needs_noise and get_flow_matcher("schrodinger").sigma == 1.0
+    with pytest.raises(ValueError):
+        get_flow_matcher("schrodinger", sigma=0.0)       # vita.yaml's sigma: 0.0 is rejected by torchcfm's bridge matcher too
     # sampler-only matchers: constructor arguments as in the reference, training refused
     m = get_flow_matcher("mean", sigma=0.0, num_sampling_steps=1, flow_ratio=0.25)          # MeanFlow swallows **kwargs (:56)
     assert m.inference_only and m.flow_ratio == 0.25 and not m.use_imf and get_flow_matcher("improved_mean").use_imf
@@ -185,3 +189,19 @@ def test_task_table_matches_baseline_dims():
     for task, O_ in (("pusht", 514), ("hook_package", 533), ("robomimic_square", 555), ("thread_needle", 533)):
         cams, s, _ = TASKS[task]
         assert 512 * len(cams) + s == O_
+
+
+def test_oracle_matcher_paths_are_consistent():
+    """torchcfm's three Gaussian paths as restated in the oracle (UNPINNED): at sigma = 0 the target path's ut equals
+    x1 - eps exactly in real arithmetic; the bridge's ut reduces to x1 - x0 at t = 1/2; conditional with sigma adds sigma*eps."""
+    from oracle import vita_oracle as O
+    g = torch.Generator().manual_seed(0)
+    x0, x1, eps = (torch.randn(6, 5, generator=g, dtype=torch.float64) for _ in range(3))
+    t = torch.rand(6, generator=g, dtype=torch.float64) * 0.8 + 0.1
+    _, xt, ut = O.cfm_sample_location_and_conditional_flow(x0, x1, t, 0.0, eps, "target")
+    assert torch.allclose(ut, x1 - eps, atol=1e-12) and torch.allclose(xt, t[:, None] * x1 + (1 - t[:, None]) * eps, atol=1e-12)
+    half = torch.full((6,), 0.5, dtype=torch.float64)
+    _, xt, ut = O.cfm_sample_location_and_conditional_flow(x0, x1, half, 0.7, eps, "schrodinger")
+    assert torch.allclose(ut, x1 - x0, atol=1e-12) and torch.allclose(xt, 0.5 * (x0 + x1) + 0.35 * eps, atol=1e-12)
+    _, xt, _ = O.cfm_sample_location_and_conditional_flow(x0, x1, t, 0.3, eps, "conditional")
+    assert torch.allclose(xt, t[:, None] * x1 + (1 - t[:, None]) * x0 + 0.3 * eps, atol=1e-12)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Training leg of bench.py alone (for rocprofv3 --kernel-trace --stats): N train steps at B rows on one GPU.
-usage: python3 tools/train_profile.py [B] [steps]"""
+usage: python3 tools/train_profile.py [B] [steps] [f32|bf16|bf16_all]"""
 import os
 import sys
 import time
@@ -17,6 +17,7 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
 cfg = default_config("hook_package")
 cfg.policy.flow_matcher.name = "conditional"
+cfg.policy.gemm_dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
 S, A = cfg.task.state_dim, cfg.task.action_dim
 stats = {cfg.task.state_key: {"mean": [0.0] * S, "std": [1.0] * S}, cfg.task.action_key: {"mean": [0.0] * A, "std": [1.0] * A}}
 torch.manual_seed(0)

@@ -103,6 +103,7 @@ class LossConfig(C.Structure):
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
         ("kl_weight", C.c_float), ("gemm_bf16", C.c_int32),
+        ("fm_kind", C.c_int32), ("fm_sigma", C.c_float),
     ]
 
 
@@ -116,6 +117,7 @@ class Bf16Weights(C.Structure):
 
 
 ENC_CNN, ENC_SIMPLE = 0, 1
+FM_CONDITIONAL, FM_TARGET, FM_SCHRODINGER = 0, 1, 2
 LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "enc_contrastive_loss",
               "flow_contrastive_loss", "action_kl_loss")
 LOSS_COUNT = 8
@@ -154,8 +156,11 @@ SIGNATURES = {
                                                   C.c_float, C.c_int32, c_fp, C.c_int64, C.c_int32, c_fp, c_fp, C.c_int64, c_fp]),
     "vita_compute_loss_workspace_bytes": (C.c_size_t, [C.POINTER(PolicyWeights), C.POINTER(LossConfig), C.c_int32]),
     "vita_compute_loss_f32": (C.c_int, [C.POINTER(PolicyWeights), C.POINTER(PolicyWeights), C.POINTER(LossConfig), c_fp, C.c_int64,
-                                        c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp, C.c_int64, C.POINTER(c_fp), c_fp,
+                                        c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp, C.c_int64, C.POINTER(c_fp), c_fp,
                                         C.c_size_t, c_fp]),
+    "vita_fm_interpolate_f32": (C.c_int, [C.c_int32, C.c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, c_fp]),
+    "vita_fm_interpolate_bwd_f32": (C.c_int, [C.c_int32, C.c_double, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32,
+                                              c_fp]),
     "vita_action_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderWeights), C.c_int32]),
     "vita_action_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderWeights), c_fp, c_fp, C.c_int64, C.c_int32, c_fp, C.c_size_t,
                                                   c_fp]),

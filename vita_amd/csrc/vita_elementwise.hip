@@ -135,6 +135,47 @@ __global__ __launch_bounds__(EW_THREADS) void cfm_kernel(const float* __restrict
     }
 }
 
+// torchcfm 1.0.5 sample_location_and_conditional_flow for the three Gaussian-path matchers the reference registers
+// (flow_matchers.py:82-99, 137-145), op for op (RESTATED from the published source, UNPINNED: torchcfm is not in the image):
+//   conditional / exact   mu = t*x1 + (1-t)*x0 ; xt = mu + sigma*eps                 ; ut = x1 - x0
+//   target                mu = t*x1            ; st = 1 - (1-sigma)*t ; xt = mu + st*eps ; ut = (x1 - (1-sigma)*xt) / st
+//   schrodinger           mu as conditional    ; st = sigma*sqrt(t*(1-t)) ; xt = mu + st*eps ;
+//                         ut = (1-2t)/(2*t*(1-t) + 1e-8) * (xt - mu) + x1 - x0
+// eps is the randn_like(x0) draw, indexed by output row; NULL only for conditional with sigma = 0 (then + 0*eps is exact).
+template <int KIND>
+__global__ __launch_bounds__(EW_THREADS) void fm_kernel(const float* __restrict__ x0, const float* __restrict__ x1, const float* __restrict__ t,
+                                                      const float* __restrict__ eps, const int64_t* __restrict__ pi,
+                                                      const int64_t* __restrict__ pj, float* __restrict__ xt, float* __restrict__ ut, int B, int D,
+                                                      float sigma, float oms) {
+    const int64_t n = (int64_t)B * D;
+    const int64_t stride = (int64_t)gridDim.x * EW_THREADS;
+    for (int64_t i = (int64_t)blockIdx.x * EW_THREADS + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const int64_t r0 = pi ? pi[r] : r;
+        const int64_t r1 = pj ? pj[r] : r;
+        const float a = x0[r0 * D + c], b = x1[r1 * D + c], tt = t[r];
+        const float e = eps ? eps[i] : 0.f;
+        if constexpr (KIND == VITA_FM_CONDITIONAL) {
+            const float mu = tt * b + (1.0f - tt) * a;
+            xt[i] = eps ? mu + sigma * e : mu;
+            ut[i] = b - a;
+        } else if constexpr (KIND == VITA_FM_TARGET) {
+            const float mu = tt * b;
+            const float st = 1.0f - oms * tt;
+            const float x = mu + st * e;
+            xt[i] = x;
+            ut[i] = (b - oms * x) / st;
+        } else {
+            const float mu = tt * b + (1.0f - tt) * a;
+            const float st = sigma * sqrtf(tt * (1.0f - tt));
+            const float x = mu + st * e;
+            const float rr = (1.0f - 2.0f * tt) / (2.0f * tt * (1.0f - tt) + 1e-8f);
+            xt[i] = x;
+            ut[i] = rr * (x - mu) + b - a;
+        }
+    }
+}
+
 // ---- (un)normalise ---------------------------------------------------------------------------
 template <bool UN>
 __global__ __launch_bounds__(EW_THREADS) void norm_kernel(const float* __restrict__ x, const float* __restrict__ mean,
@@ -525,6 +566,26 @@ int vita_cfm_interpolate_f32(const float* x0, const float* x1, const float* t, c
     if (B == 0) return VITA_OK;
     hipLaunchKernelGGL(cfm_kernel, dim3(ew_grid((int64_t)B * D)), dim3(EW_THREADS), 0, (hipStream_t)stream, x0, x1, t, pair_i, pair_j, xt,
                        ut, B, D);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+int vita_fm_interpolate_f32(int32_t kind, double sigma, const float* x0, const float* x1, const float* t, const float* eps,
+                            const int64_t* pair_i, const int64_t* pair_j, float* xt, float* ut, int32_t B, int32_t D, vita_stream_t stream) {
+    const char* who = "vita_fm_interpolate_f32";
+    VITA_REQUIRE(kind >= VITA_FM_CONDITIONAL && kind <= VITA_FM_SCHRODINGER, "%s: unknown matcher kind %d", who, kind);
+    VITA_REQUIRE(x0 && x1 && t && xt && ut, "%s: null pointer", who);
+    VITA_REQUIRE(B >= 0 && D > 0, "%s: bad shape B=%d D=%d", who, B, D);
+    VITA_REQUIRE(sigma >= 0.0, "%s: sigma must be >= 0", who);
+    VITA_REQUIRE(kind != VITA_FM_SCHRODINGER || sigma > 0.0, "%s: Sigma must be strictly positive, got %g.", who, sigma);
+    VITA_REQUIRE(eps != nullptr || (kind == VITA_FM_CONDITIONAL && sigma == 0.0), "%s: this matcher adds noise to xt: eps (B, D) is required", who);
+    if (B == 0) return VITA_OK;
+    const dim3 grid(ew_grid((int64_t)B * D)), block(EW_THREADS);
+    const float sg = (float)sigma, oms = (float)(1.0 - sigma);
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == VITA_FM_CONDITIONAL) hipLaunchKernelGGL((fm_kernel<VITA_FM_CONDITIONAL>), grid, block, 0, s, x0, x1, t, eps, pair_i, pair_j, xt, ut, B, D, sg, oms);
+    else if (kind == VITA_FM_TARGET) hipLaunchKernelGGL((fm_kernel<VITA_FM_TARGET>), grid, block, 0, s, x0, x1, t, eps, pair_i, pair_j, xt, ut, B, D, sg, oms);
+    else hipLaunchKernelGGL((fm_kernel<VITA_FM_SCHRODINGER>), grid, block, 0, s, x0, x1, t, eps, pair_i, pair_j, xt, ut, B, D, sg, oms);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }

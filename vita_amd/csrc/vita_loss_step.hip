@@ -537,7 +537,7 @@ size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vit
 
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t, const int64_t* pair_i,
-                          const int64_t* pair_j, const float* enc_noise, int32_t B, float* losses, float* d_obs_features, int64_t ld_dobs,
+                          const int64_t* pair_j, const float* fm_noise, const float* enc_noise, int32_t B, float* losses, float* d_obs_features, int64_t ld_dobs,
                           void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream) {
     const char* who = "vita_compute_loss_f32";
     VITA_TRY(check_policy(w, who));
@@ -549,6 +549,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
                  "%s: negative contrastive weight / temperature", who);
     VITA_REQUIRE(B >= 1, "%s: B must be >= 1 (the mean over an empty batch is undefined)", who);
     VITA_REQUIRE(cfg->kl_weight >= 0.f && cfg->gemm_bf16 >= 0 && cfg->gemm_bf16 <= 2, "%s: bad kl_weight / gemm_bf16", who);
+    VITA_REQUIRE(cfg->fm_kind >= VITA_FM_CONDITIONAL && cfg->fm_kind <= VITA_FM_SCHRODINGER && cfg->fm_sigma >= 0.f, "%s: bad fm_kind / fm_sigma", who);
     VITA_REQUIRE(enc_noise == nullptr || w->enc.variational, "%s: enc_noise is the variational encoder's draw; this encoder is not variational", who);
     VITA_REQUIRE(obs_features && actions && t && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/losses", who);
     VITA_REQUIRE(d_obs_features == nullptr || (grads != nullptr && ld_dobs >= w->O), "%s: d_obs_features needs grads and ld_dobs >= O", who);
@@ -605,7 +606,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     if (K > 0) VITA_TRY(launch_step_times(s.flow.ts + B, K, st));
     VITA_TRY(time_path_fwd(fc, T));
     // flow-matching loss, flow_matchers.py:30-36
-    VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
+    const bool plain_cfm = cfg->fm_kind == VITA_FM_CONDITIONAL && cfg->fm_sigma == 0.f;
+    if (plain_cfm) VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
+    else VITA_TRY(vita_fm_interpolate_f32(cfg->fm_kind, (double)cfg->fm_sigma, s.z0, z1, t, fm_noise, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
     VITA_TRY(flow_eval_fwd(fc, 0, s.flow.mod, ldm, s.vt, D, nullptr, 0, 0.f));
     VITA_TRY(vita_mse_loss_fwd_f32(s.vt, s.ut, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_FLOW, st));
     if (nce_enc) VITA_TRY(nce_forward(s.z0, D, z1, D, B, D, tau, losses + VITA_LOSS_ENC_CONTRASTIVE, s.nce_enc, st));              // :134-139
@@ -693,7 +696,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     } else {
         VITA_CHECK_HIP(hipMemsetAsync(s.dz0, 0, (size_t)B * D * 4, st));
     }
-    VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
+    if (plain_cfm) VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
+    else VITA_TRY(vita_fm_interpolate_bwd_f32(cfg->fm_kind, (double)cfg->fm_sigma, s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
     if (nce_enc || nce_flow) VITA_TRY(launch_axpy(s.dz0c, s.dz0, (int64_t)B * D, st));
     VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
     VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));

@@ -250,6 +250,32 @@ __global__ __launch_bounds__(TT) void cfm_bwd_kernel(const float* __restrict__ d
     }
 }
 
+// backward of fm_kernel (vita_elementwise.hip).  conditional and schrodinger: d xt / d(x0, x1) = (1-t, t), d ut / d(x0, x1) =
+// (-1, 1) (the bridge's extra term r*(xt - mu) = r*st*eps does not depend on x0, x1); target: x0 takes no part,
+// d xt / d x1 = t, d ut / d x1 = 1/st and d ut / d xt = -(1-sigma)/st.
+template <int KIND>
+__global__ __launch_bounds__(TT) void fm_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ dut, const float* __restrict__ t,
+                                                   const int64_t* __restrict__ pi, const int64_t* __restrict__ pj, float* __restrict__ dx0,
+                                                   float* __restrict__ dx1, int B, int D, int accumulate, float oms) {
+    const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * TT;
+    for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
+        const int r = (int)(i / D), c = (int)(i - (int64_t)r * D);
+        const float a = dxt ? dxt[i] : 0.f, u = dut ? dut[i] : 0.f, tt = t[r];
+        float g0, g1;
+        if constexpr (KIND == VITA_FM_TARGET) {
+            const float st = 1.0f - oms * tt;
+            const float q = u / st;
+            g0 = 0.f;
+            g1 = q + tt * (a - oms * q);
+        } else {
+            g0 = (1.0f - tt) * a - u;
+            g1 = tt * a + u;
+        }
+        if (dx0) { if (pi) atomicAdd(&dx0[pi[r] * D + c], g0); else dx0[i] = accumulate ? dx0[i] + g0 : g0; }
+        if (dx1) { if (pj) atomicAdd(&dx1[pj[r] * D + c], g1); else dx1[i] = accumulate ? dx1[i] + g1 : g1; }
+    }
+}
+
 // ---- sum of squares (gradient norm), two-stage ------------------------------------------------------
 __global__ __launch_bounds__(TT) void sumsq_stage1(const float* __restrict__ x, int64_t n, float* __restrict__ part) {
     float s = 0.f;
@@ -419,6 +445,23 @@ int vita_cfm_interpolate_bwd_f32(const float* dxt, const float* dut, const float
         if (dx1 && pair_j) VITA_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)B * D * 4, st));
     }
     hipLaunchKernelGGL(cfm_bwd_kernel, dim3(tgrid((int64_t)B * D)), dim3(TT), 0, st, dxt, dut, t, pair_i, pair_j, dx0, dx1, B, D, accumulate);
+    LAUNCH_OK();
+}
+int vita_fm_interpolate_bwd_f32(int32_t kind, double sigma, const float* dxt, const float* dut, const float* t, const int64_t* pair_i,
+                                const int64_t* pair_j, float* dx0, float* dx1, int32_t B, int32_t D, int32_t accumulate, vita_stream_t s) {
+    const char* who = "vita_fm_interpolate_bwd_f32";
+    VITA_REQUIRE(kind >= VITA_FM_CONDITIONAL && kind <= VITA_FM_SCHRODINGER, "%s: unknown matcher kind %d", who, kind);
+    VITA_REQUIRE(t && (dxt || dut) && (dx0 || dx1) && B >= 0 && D > 0 && sigma >= 0.0, "%s: bad arguments", who);
+    if (B == 0) return VITA_OK;
+    if (!accumulate) {
+        if (dx0 && pair_i) VITA_CHECK_HIP(hipMemsetAsync(dx0, 0, (size_t)B * D * 4, (hipStream_t)s));
+        if (dx1 && pair_j) VITA_CHECK_HIP(hipMemsetAsync(dx1, 0, (size_t)B * D * 4, (hipStream_t)s));
+    }
+    const float oms = (float)(1.0 - sigma);
+    if (kind == VITA_FM_TARGET)
+        hipLaunchKernelGGL((fm_bwd_kernel<VITA_FM_TARGET>), dim3(tgrid((int64_t)B * D)), dim3(TT), 0, (hipStream_t)s, dxt, dut, t, pair_i, pair_j, dx0, dx1, B, D, accumulate, oms);
+    else
+        hipLaunchKernelGGL((fm_bwd_kernel<VITA_FM_CONDITIONAL>), dim3(tgrid((int64_t)B * D)), dim3(TT), 0, (hipStream_t)s, dxt, dut, t, pair_i, pair_j, dx0, dx1, B, D, accumulate, oms);
     LAUNCH_OK();
 }
 int vita_sumsq_f32(const float* x, int64_t n, float* partials, float* out, vita_stream_t s) {

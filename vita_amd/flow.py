@@ -5,6 +5,7 @@ num_sampling_steps=...)`, `FLOW_MATCHER_CLASSES`, `.sample(model, shape, device,
 start)`, `.compute_loss(model, target, start)`), but `model` is a `vita_amd.ops.FlowNetHandle` and the arithmetic
 runs in libvita_hip.so: `.sample` is ONE C-ABI call that enqueues all K Euler steps.
 
+All four torchcfm-backed names are built (conditional, exact, target, schrodinger; any sigma >= 0).
 What stays on the host, as in the reference: the flow-matching draw.  torchcfm==1.0.5 (absent from this image;
 restated from its published source, UNPINNED) draws t with `torch.rand(B).type_as(x0)` on the CPU generator and,
 for the `exact` matcher, solves a minibatch OT plan with POT's `ot.emd` on numpy and samples B pairs from it
@@ -19,6 +20,7 @@ from typing import Optional
 import numpy as np
 import torch
 
+from . import _lib as L
 from . import ops
 
 
@@ -47,32 +49,43 @@ def exact_ot_pairing(x0: torch.Tensor, x1: torch.Tensor):
 
 
 class TorchFlowMatcher:
-    """flow_matchers.py:10-79."""
+    """flow_matchers.py:10-79 over torchcfm==1.0.5's ConditionalFlowMatcher family (restated, UNPINNED)."""
 
     pairing = "identity"
+    kind = L.FM_CONDITIONAL
+    default_sigma = 0.0
 
-    def __init__(self, num_sampling_steps: int = 6, sigma: float = 0.0, **kwargs):
+    def __init__(self, num_sampling_steps: int = 6, sigma=None, **kwargs):
         if kwargs:
             raise TypeError(f"unexpected flow matcher arguments: {sorted(kwargs)}")
-        if float(sigma) != 0.0:
-            raise NotImplementedError("vita_amd implements the sigma=0 path (vita.yaml:24); sigma > 0 adds sigma*eps to xt")
-        self.sigma = float(sigma)
+        self.sigma = float(self.default_sigma if sigma is None else sigma)
+        if self.sigma < 0.0:
+            raise ValueError(f"sigma must be >= 0, got {self.sigma}")
         self.num_sampling_steps = num_sampling_steps
+
+    @property
+    def needs_noise(self) -> bool:
+        """Whether xt depends on the eps = randn_like(x0) draw (torchcfm always draws it; with the conditional path and
+        sigma = 0 it is multiplied by zero, so the draw is skipped here)."""
+        return self.kind != L.FM_CONDITIONAL or self.sigma != 0.0
 
     # -- the draw (host) ---------------------------------------------------------------
     def draw(self, x0: torch.Tensor, x1: torch.Tensor):
-        """(t, pair_i, pair_j) for one compute_loss call; pair_* are None for the identity pairing."""
+        """(t, pair_i, pair_j, eps) for one compute_loss call in torchcfm's order: OT plan (numpy RNG), t = torch.rand (CPU
+        generator), eps = randn_like(x0) (device generator).  pair_* are None for the identity pairing, eps None when unused."""
         pi = pj = None
         if self.pairing == "exact":
             pi, pj = exact_ot_pairing(x0.detach(), x1.detach())
-        return draw_t(x0.shape[0], x0), pi, pj
+        t = draw_t(x0.shape[0], x0)
+        eps = torch.randn_like(x0) if self.needs_noise else None
+        return t, pi, pj, eps
 
     # -- reference API -----------------------------------------------------------------
     def compute_loss(self, model: "ops.FlowNetHandle", target: torch.Tensor, start: Optional[torch.Tensor] = None, **kwargs):
         """flow_matchers.py:19-39 (forward only; training uses the fused vita_compute_loss_f32)."""
         x0 = torch.randn_like(target) if start is None else start
-        t, pi, pj = self.draw(x0, target)
-        xt, ut = ops.cfm_interpolate(x0, target, t, pair_j=pj, pair_i=pi)
+        t, pi, pj, eps = self.draw(x0, target)
+        xt, ut = ops.fm_interpolate(self.kind, self.sigma, x0, target, t, eps, pair_j=pj, pair_i=pi)
         vt = ops.flownet_forward(model, xt, t)
         loss = ops.mse_loss_fwd(vt, ut)
         return loss, {"loss": loss.item()}
@@ -100,11 +113,36 @@ class ExactOptimalTransportConditionalFlowMatcher(TorchFlowMatcher):
     pairing = "exact"
 
 
+class TargetConditionalFlowMatcher(TorchFlowMatcher):
+    """flow_matchers.py:87-89 -> torchcfm TargetConditionalFlowMatcher (Lipman et al.): mu_t = t*x1,
+    sigma_t = 1 - (1-sigma)*t, ut = (x1 - (1-sigma)*xt) / (1 - (1-sigma)*t); x0 only lends its shape."""
+    kind = L.FM_TARGET
+
+
+class SchrodingerBridgeConditionalFlowMatcher(TorchFlowMatcher):
+    """flow_matchers.py:92-94 -> torchcfm SchrodingerBridgeConditionalFlowMatcher(sigma=1.0, ot_method='exact'): the
+    minibatch-OT pairing of the exact matcher (ot.emd ignores the entropic `reg`), a Brownian-bridge xt and its
+    conditional flow.  sigma must be > 0 (vita.yaml's flow_matcher.sigma: 0.0 has to be overridden, as in the reference)."""
+    kind = L.FM_SCHRODINGER
+    pairing = "exact"
+    default_sigma = 1.0
+
+    def __init__(self, num_sampling_steps: int = 6, sigma=None, ot_method: str = "exact", **kwargs):
+        super().__init__(num_sampling_steps, sigma, **kwargs)
+        if self.sigma <= 0:
+            raise ValueError(f"Sigma must be strictly positive, got {self.sigma}.")
+        if ot_method != "exact":
+            raise NotImplementedError("schrodinger matcher: only ot_method='exact' (torchcfm's default) is built")
+
+
 class _InferenceOnlyMatcher:
     """Matchers whose sampler is built and whose training loss is not (SURVEY.md 8(a) a16 / 8(f) #4)."""
 
     inference_only = True
     pairing = "identity"
+
+    needs_noise = False
+    kind, sigma = L.FM_CONDITIONAL, 0.0
 
     def draw(self, x0, x1):
         raise NotImplementedError(f"{type(self).__name__}: the training loss of this matcher is not built")
@@ -186,20 +224,11 @@ class ConsistencyFlowMatcher(_InferenceOnlyMatcher):
                                       noise=noise)
 
 
-def _not_yet(name):
-    class _NotBuilt:
-        def __init__(self, *a, **k):
-            raise NotImplementedError(
-                f"flow matcher '{name}' is outside this build's hot path (SURVEY.md 8(f)); use 'exact' or 'conditional'")
-    _NotBuilt.__name__ = name
-    return _NotBuilt
-
-
 FLOW_MATCHER_CLASSES = {                       # flow_matchers.py:137-145
     "conditional": ConditionalFlowMatcher,
     "exact": ExactOptimalTransportConditionalFlowMatcher,
-    "target": _not_yet("target"),
-    "schrodinger": _not_yet("schrodinger"),
+    "target": TargetConditionalFlowMatcher,
+    "schrodinger": SchrodingerBridgeConditionalFlowMatcher,
     "mean": MeanFlowConditionalFlowMatcher,
     "improved_mean": ImprovedMeanFlowConditionalFlowMatcher,
     "consistency": ConsistencyFlowMatcher,

@@ -465,6 +465,42 @@ def cfm_interpolate(x0: Tensor, x1: Tensor, t: Tensor, pair_j: Optional[Tensor] 
     return xt, ut
 
 
+def fm_interpolate(kind: int, sigma: float, x0: Tensor, x1: Tensor, t: Tensor, eps: Optional[Tensor] = None,
+                   pair_j: Optional[Tensor] = None, pair_i: Optional[Tensor] = None):
+    """(xt, ut) of torchcfm's conditional / target / Schrodinger-bridge matchers (vita_fm_interpolate_f32; kind = _lib.FM_*)."""
+    lib = L.load()
+    x0 = _f32(x0, "fm_interpolate").contiguous()
+    x1 = _f32(x1, "fm_interpolate").contiguous()
+    t = _f32(t, "fm_interpolate").contiguous()
+    if eps is not None:
+        eps = _f32(eps, "fm_interpolate: eps").contiguous()
+        if eps.shape != x0.shape:
+            raise L.VitaHipError(f"fm_interpolate: eps {tuple(eps.shape)} must match x0 {tuple(x0.shape)}")
+    B, D = x0.shape
+    pair_i, pair_j = _idx(pair_i, x0.device), _idx(pair_j, x0.device)
+    xt = torch.empty_like(x0)
+    ut = torch.empty_like(x0)
+    L.check(lib.vita_fm_interpolate_f32(int(kind), float(sigma), x0.data_ptr(), x1.data_ptr(), t.data_ptr(),
+                                        eps.data_ptr() if eps is not None else None,
+                                        pair_i.data_ptr() if pair_i is not None else None,
+                                        pair_j.data_ptr() if pair_j is not None else None,
+                                        xt.data_ptr(), ut.data_ptr(), B, D, _stream(x0)), "vita_fm_interpolate_f32")
+    return xt, ut
+
+
+def fm_interpolate_bwd(kind: int, sigma: float, dxt: Tensor, dut: Tensor, t: Tensor, pair_j=None, pair_i=None):
+    lib = L.load()
+    dxt, dut, t = dxt.contiguous(), dut.contiguous(), t.contiguous()
+    B, D = dxt.shape
+    pair_i, pair_j = _idx(pair_i, dxt.device), _idx(pair_j, dxt.device)
+    d0, d1 = torch.empty_like(dxt), torch.empty_like(dxt)
+    L.check(lib.vita_fm_interpolate_bwd_f32(int(kind), float(sigma), dxt.data_ptr(), dut.data_ptr(), t.data_ptr(),
+                                            pair_i.data_ptr() if pair_i is not None else None,
+                                            pair_j.data_ptr() if pair_j is not None else None,
+                                            d0.data_ptr(), d1.data_ptr(), B, D, 0, _stream(dxt)), "vita_fm_interpolate_bwd_f32")
+    return d0, d1
+
+
 def _norm(fn_name: str, x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
     """Stats of shape (C) act on the last dim; stats of shape (C,1,..,1) act on dim -mean.dim() (image statistics)."""
     lib = L.load()
@@ -794,7 +830,8 @@ class PolicyHandle:
 def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
                 enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, enc_contrastive_weight: float = 0.0,
                 flow_contrastive_weight: float = 0.0, temperature: float = 0.07, freeze_encoder: bool = False,
-                freeze_decoder: bool = False, kl_weight: float = 0.0, gemm_bf16: int = 0) -> "L.LossConfig":
+                freeze_decoder: bool = False, kl_weight: float = 0.0, gemm_bf16: int = 0, fm_kind: int = 0,
+                fm_sigma: float = 0.0) -> "L.LossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")   # vita_policy.py:71
     c = L.LossConfig()
@@ -803,12 +840,13 @@ def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool
     c.enc_contrastive_weight, c.flow_contrastive_weight, c.temperature = enc_contrastive_weight, flow_contrastive_weight, temperature
     c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
     c.kl_weight, c.gemm_bf16 = float(kl_weight), int(gemm_bf16)
+    c.fm_kind, c.fm_sigma = int(fm_kind), float(fm_sigma)
     return c
 
 
 def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, *, grads: Optional[PolicyHandle] = None,
                  pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None,
-                 enc_noise: Optional[Tensor] = None):
+                 enc_noise: Optional[Tensor] = None, fm_noise: Optional[Tensor] = None):
     """VitaPolicy.compute_loss (+ backward when `grads` is given), vita_policy.py:112-189.  Returns
     (losses (8,) device tensor indexed as _lib.LOSS_NAMES, d_obs_features or None).  No host sync."""
     lib = L.load()
@@ -825,6 +863,12 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
         enc_noise = _f32(enc_noise, "compute_loss: enc_noise").contiguous()
         if tuple(enc_noise.shape) != (B, pw.D):
             raise L.VitaHipError(f"compute_loss: enc_noise {tuple(enc_noise.shape)} must be (B, D) = ({B}, {pw.D})")
+    if fm_noise is not None:
+        fm_noise = _f32(fm_noise, "compute_loss: fm_noise").contiguous()
+        if tuple(fm_noise.shape) != (B, pw.D):
+            raise L.VitaHipError(f"compute_loss: fm_noise {tuple(fm_noise.shape)} must be (B, D) = ({B}, {pw.D})")
+    elif cfg.fm_kind != L.FM_CONDITIONAL or cfg.fm_sigma != 0.0:
+        raise L.VitaHipError("compute_loss: this flow matcher adds noise to xt: pass fm_noise (B, D)")
     if losses is None:
         losses = torch.empty(L.LOSS_COUNT, dtype=torch.float32, device=dev)
     dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
@@ -844,6 +888,7 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
                                       obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(),
                                       pair_i.data_ptr() if pair_i is not None else None,
                                       pair_j.data_ptr() if pair_j is not None else None,
+                                      fm_noise.data_ptr() if fm_noise is not None else None,
                                       enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
                                       dobs.data_ptr() if dobs is not None else None, pw.O, ev, ws.data_ptr(), ws.numel(),
                                       _stream(obs_features)), "vita_compute_loss_f32")

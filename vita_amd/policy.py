@@ -204,13 +204,13 @@ class _FusedLoss(torch.autograd.Function):
     fused forward+backward; backward hands the staged gradients to autograd (scaled by the incoming grad)."""
 
     @staticmethod
-    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, enc_noise, *params):
+    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, *params):
         pw, gw, gsd = policy._train_handles(stage=True)
         frozen = policy.frozen_prefixes()
         staged = [None if k.startswith(frozen) else gsd[k] for k, _ in policy.hot_path_named_parameters()]
         need_dobs = obs_features.requires_grad
         losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
-                                        need_dobs=need_dobs, enc_noise=enc_noise)
+                                        need_dobs=need_dobs, enc_noise=enc_noise, fm_noise=fm_noise)
         ctx.staged, ctx.dobs = staged, dobs
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
@@ -219,7 +219,7 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, gout, _):
         grads = tuple((g * gout if g is not None else None) for g in ctx.staged)
         dobs = ctx.dobs * gout if ctx.dobs is not None else None
-        return (None, dobs, None, None, None, None, None) + grads
+        return (None, dobs, None, None, None, None, None, None) + grads
 
 
 class VitaPolicy(nn.Module):
@@ -298,7 +298,8 @@ class VitaPolicy(nn.Module):
                                          freeze_encoder=bool(self.freeze_action_encoder),
                                          freeze_decoder=bool(self.freeze_action_decoder),
                                          kl_weight=float(self.action_kl_weight) if self.use_action_vae else 0.0,
-                                         gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype])
+                                         gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype],
+                                         fm_kind=int(self.FM.kind), fm_sigma=float(self.FM.sigma))
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -427,10 +428,11 @@ class VitaPolicy(nn.Module):
         return self.compute_loss(batch)
 
     # -- the hot path -----------------------------------------------------------------------------------
-    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None, enc_noise=None):
+    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None, enc_noise=None, fm_noise=None):
         """The host-side random draws of one compute_loss call, in the reference's order: the variational posterior's
         eps (torch.randn_like on the device, dists.py:20; training mode only, vita_policy.py:121), then t ~ U(0,1) and the
-        OT pairing (flow_matchers.py:34 -> torchcfm).  Returns (t, pair_i, pair_j, enc_noise)."""
+        OT pairing (flow_matchers.py:34 -> torchcfm), then the matcher's eps = randn_like(x0) when its xt uses it (sigma > 0,
+        target, schrodinger).  Returns (t, pair_i, pair_j, enc_noise, fm_noise)."""
         if self.use_action_vae and self.training and enc_noise is None:
             enc_noise = torch.randn(batch_size, self.latent_dim, device=dev)
         if not (self.use_action_vae and self.training):
@@ -447,9 +449,14 @@ class VitaPolicy(nn.Module):
                 z1 = mean if enc_noise is None else mean + torch.exp(0.5 * logvar) * enc_noise
             from .flow import exact_ot_pairing
             pair_i, pair_j = exact_ot_pairing(z0, z1)
-        return t, pair_i, pair_j, enc_noise
+        if self.FM.needs_noise and fm_noise is None:
+            fm_noise = torch.randn(batch_size, self.latent_dim, device=dev)
+        if not self.FM.needs_noise:
+            fm_noise = None
+        return t, pair_i, pair_j, enc_noise, fm_noise
 
-    def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None, enc_noise=None):
+    def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None, enc_noise=None,
+                       fm_noise=None):
         """Native training entry (no autograd): normalised batch -> losses (device float[8], _lib.LOSS_NAMES order), with
         d loss / d parameter written into the parameters' .grad buffers.  No host synchronisation."""
         if self.inference_only:
@@ -457,17 +464,17 @@ class VitaPolicy(nn.Module):
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
-        t, pair_i, pair_j, enc_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions,
-                                                  enc_noise)
+        t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
+                                                            actions, enc_noise, fm_noise)
         pw, gw, gsd = self._train_handles()
         if self._flat_grad is None:
             for (k, p) in self.hot_path_named_parameters():
                 p.grad = gsd[k]
         out, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
-                                  grad_ready_events=grad_ready_events, losses=losses, enc_noise=enc_noise)
+                                  grad_ready_events=grad_ready_events, losses=losses, enc_noise=enc_noise, fm_noise=fm_noise)
         return out
 
-    def compute_loss(self, batch, *, t=None, pair_i=None, pair_j=None, enc_noise=None):
+    def compute_loss(self, batch, *, t=None, pair_i=None, pair_j=None, enc_noise=None, fm_noise=None):
         """vita_policy.py:112-189.  Returns (loss, metrics) with the reference's metric keys; `loss` supports
         .backward() (drop-in for policy_trainer.py:79-82).  One device->host copy for all metrics (the reference
         does one .item() per metric)."""
@@ -476,14 +483,15 @@ class VitaPolicy(nn.Module):
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
-        t, pair_i, pair_j, enc_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features, actions,
-                                                  enc_noise)
+        t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
+                                                            actions, enc_noise, fm_noise)
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
             params = [p for _, p in self.hot_path_named_parameters()]
-            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, *params)
+            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, *params)
         else:
             _, _, pw = self._infer_handles()
-            losses, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise)
+            losses, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise,
+                                         fm_noise=fm_noise)
             loss = losses[0]
         vals = losses.detach().cpu().tolist()
         metrics = {"loss": vals[1], "flow_loss": vals[1]}   # FM.compute_loss's own 'loss' entry is the flow loss (flow_matchers.py:39)
