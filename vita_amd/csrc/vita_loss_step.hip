@@ -208,7 +208,9 @@ struct FlowTrainWs {
 };
 FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B, size_t K, bool train) {
     FlowTrainWs f{};
-    const size_t T = B + K, E = 1 + K, H = w.H, FF = w.FF, D = w.D, L = w.L, TE = w.TE;
+    // time-path rows: the B per-row timesteps of the flow-matching evaluation, B more for Euler step 0 (t = 0; it is evaluated
+    // together with the flow-matching rows, see vita_compute_loss_f32), one per later step
+    const size_t T = K > 0 ? 2 * B + K - 1 : B, E = 1 + K, H = w.H, FF = w.FF, D = w.D, L = w.L, TE = w.TE;
     f.ts = c.take(T);
     f.sin = c.take(T * TE);
     f.hidpre = c.take(T * 4 * TE);
@@ -231,7 +233,7 @@ FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B,
         f.DH0 = c.take(E * B * H);
         f.DHNF = c.take(E * B * H);
         f.RN = c.take(E * B * H);
-        f.dhn = c.take(B * H);
+        f.dhn = c.take(2 * B * H);
         f.DM = c.take(B * L * 3 * H);
     }
     return f;
@@ -303,12 +305,11 @@ int time_path_bwd(const FlowCtx& c, const vita_flownet_weights& g, int T, float*
     return VITA_OK;
 }
 
-// SimpleFlowNet.forward (simple_flow_net.py:99-108) for evaluation e, saving what the backward needs.
-// Y = resid + dt * v when resid != NULL (flow_matchers.py:71), else Y = v.
-int flow_eval_fwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, float* Y, int64_t ldy, const float* resid,
-                  int64_t ld_resid, float dt) {
+// SimpleFlowNet.forward (simple_flow_net.py:99-108) up to the final norm for the M rows that start at evaluation e (M = B, or
+// n*B for n consecutive evaluations: their rows are adjacent in every stacked buffer), saving what the backward needs.
+int flow_trunk_fwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_mod) {
     const vita_flownet_weights* w = c.w;
-    const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = c.B;
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = M;
     VITA_TRY(gemm_f32(lin(c.X(e), D, w->in_w, D, w->in_b, c.Hs(0, e), H, B, H, D, VITA_ACT_NONE), c.st));
     for (int l = 0; l < L; ++l) {
         const float* gamma = mod + (size_t)l * 3 * H;
@@ -323,19 +324,30 @@ int flow_eval_fwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, flo
         b.gate = gamma; b.ld_gate = ld_mod; b.resid = c.Hs(l, e); b.ld_resid = H;
         VITA_TRY(gemm_f32(b, c.st));
     }
-    VITA_TRY(launch_ln_mod(c.Hs(L, e), H, c.HN(L, e), H, B, H, 1e-5f, VITA_PRO_LN_AFFINE, w->norm_w, 0, w->norm_b, 0, c.st));
+    return launch_ln_mod(c.Hs(L, e), H, c.HN(L, e), H, B, H, 1e-5f, VITA_PRO_LN_AFFINE, w->norm_w, 0, w->norm_b, 0, c.st);
+}
+// out_proj of evaluation e (B rows): Y = resid + dt * v when resid != NULL (flow_matchers.py:71), else Y = v.
+int flow_out_fwd(const FlowCtx& c, int e, float* Y, int64_t ldy, const float* resid, int64_t ld_resid, float dt) {
+    const vita_flownet_weights* w = c.w;
+    const int D = w->D, H = w->H, L = w->L, B = c.B;
     vita_linear_args o = lin(c.HN(L, e), H, w->out_w, H, w->out_b, Y, ldy, B, D, H, VITA_ACT_NONE);
     if (resid) { o.use_gate_scalar = 1; o.gate_scalar = dt; o.resid = resid; o.ld_resid = ld_resid; }
     return gemm_f32(o, c.st);
+}
+int flow_eval_fwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, float* Y, int64_t ldy, const float* resid,
+                  int64_t ld_resid, float dt) {
+    VITA_TRY(flow_trunk_fwd(c, e, c.B, mod, ld_mod));
+    return flow_out_fwd(c, e, Y, ldy, resid, ld_resid, dt);
 }
 
 // Input-gradient chain of evaluation e from DV(e) = d loss / d v.  Leaves dU in U(l,e), dY2 in Y2(l,e), dH0 in DH0(e),
 // dHNF / RN for the final norm, the modulation-row gradients in dm_rows (B, L*3H), and
 //   dx = resid + DH0 . W_in      (resid: the identity branch of the Euler update, or NULL)
-int flow_eval_bwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, float* dm_rows, float* dx, int64_t ld_dx,
-                  const float* resid, int64_t ld_resid) {
+// flow_chain_bwd: everything but the last GEMM, for the M rows that start at evaluation e (M = B or n*B, as flow_trunk_fwd);
+// flow_in_bwd: dx of evaluation e (B rows).
+int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_mod, float* dm_rows) {
     const vita_flownet_weights* w = c.w;
-    const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = c.B;
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = M;
     const int64_t ldm = (int64_t)L * 3 * H;
     VITA_TRY(gemm_f32(dgrad(c.DV(e), D, w->out_w, H, c.DHNF(e), H, B, H, D), c.st));
     VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(L, e), H, c.DHNF(e), H, w->norm_w, 0, B, H, 1e-5f, VITA_PRO_LN_AFFINE, c.DH0(e), H, 0,
@@ -353,9 +365,18 @@ int flow_eval_bwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, flo
         VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(l, e), H, c.f.dhn, H, scale, ld_mod, B, H, 1e-6f, VITA_PRO_LN_MOD, c.DH0(e), H, 1,
                                                  dmr + H, dmr + 2 * H, ldm, c.st));
     }
-    vita_linear_args a = dgrad(c.DH0(e), H, w->in_w, D, dx, ld_dx, B, D, H);
+    return VITA_OK;
+}
+int flow_in_bwd(const FlowCtx& c, int e, float* dx, int64_t ld_dx, const float* resid, int64_t ld_resid) {
+    const vita_flownet_weights* w = c.w;
+    vita_linear_args a = dgrad(c.DH0(e), w->H, w->in_w, w->D, dx, ld_dx, c.B, w->D, w->H);
     if (resid) { a.resid = resid; a.ld_resid = ld_resid; }
     return gemm_f32(a, c.st);
+}
+int flow_eval_bwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, float* dm_rows, float* dx, int64_t ld_dx,
+                  const float* resid, int64_t ld_resid) {
+    VITA_TRY(flow_chain_bwd(c, e, c.B, mod, ld_mod, dm_rows));
+    return flow_in_bwd(c, e, dx, ld_dx, resid, ld_resid);
 }
 
 // One wgrad GEMM + one column-sum per weight over the E*B stacked rows.
@@ -569,7 +590,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     const bool fe = cfg->freeze_encoder != 0, fd = cfg->freeze_decoder != 0;
     const bool do_sample = cfg->decode_flow_latents != 0 && !fe && !fd;                                                // :153
     const int K = do_sample ? cfg->num_steps : 0;
-    const int T = B + K;
+    const int T = K > 0 ? 2 * B + K - 1 : B;   // time-path rows: [flow-matching t (B) | step 0: zeros (B) | steps 1..K-1]
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
     const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd;                                                           // :183
@@ -603,23 +624,36 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     }
     // time path for the B per-row timesteps of the flow-matching draw and the K Euler steps
     VITA_CHECK_HIP(hipMemcpyAsync(s.flow.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
-    if (K > 0) VITA_TRY(launch_step_times(s.flow.ts + B, K, st));
+    if (K > 0) {
+        if (B > 1) VITA_CHECK_HIP(hipMemsetAsync(s.flow.ts + B, 0, (size_t)(B - 1) * 4, st));
+        VITA_TRY(launch_step_times(s.flow.ts + 2 * B - 1, K, st));   // ts[2B-1+k] = k/K; k = 0 closes the zero block
+    }
     VITA_TRY(time_path_fwd(fc, T));
+    auto step_mod = [&](int k) { return s.flow.mod + (size_t)(2 * B - 1 + k) * ldm; };   // k >= 1: one broadcast row
     // flow-matching loss, flow_matchers.py:30-36
     const bool plain_cfm = cfg->fm_kind == VITA_FM_CONDITIONAL && cfg->fm_sigma == 0.f;
     if (plain_cfm) VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
     else VITA_TRY(vita_fm_interpolate_f32(cfg->fm_kind, (double)cfg->fm_sigma, s.z0, z1, t, fm_noise, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
-    VITA_TRY(flow_eval_fwd(fc, 0, s.flow.mod, ldm, s.vt, D, nullptr, 0, 0.f));
-    VITA_TRY(vita_mse_loss_fwd_f32(s.vt, s.ut, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_FLOW, st));
-    if (nce_enc) VITA_TRY(nce_forward(s.z0, D, z1, D, B, D, tau, losses + VITA_LOSS_ENC_CONTRASTIVE, s.nce_enc, st));              // :134-139
-    // Euler sampler with grad, vita_policy.py:153-160 / flow_matchers.py:55-79
+    // The flow-matching evaluation and Euler step 0 are independent and their rows are adjacent in every stacked buffer:
+    // they run as ONE 2B-row pass with per-row modulation (one evaluation's worth of launches less per step, forward and
+    // backward; at the default B = 128 the step is launch-bound).  Only out_proj differs (v vs x + dt*v) and stays per evaluation.
     const float dt = K > 0 ? (float)(1.0 / (double)K) : 0.f;
     if (do_sample) {
         VITA_CHECK_HIP(hipMemcpyAsync(fc.X(1), s.z0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
-        for (int k = 0; k < K; ++k) {
+        VITA_TRY(flow_trunk_fwd(fc, 0, 2 * B, s.flow.mod, ldm));
+        VITA_TRY(flow_out_fwd(fc, 0, s.vt, D, nullptr, 0, 0.f));
+        VITA_TRY(flow_out_fwd(fc, 1, K == 1 ? pred : fc.X(2), D, fc.X(1), D, dt));
+    } else {
+        VITA_TRY(flow_eval_fwd(fc, 0, s.flow.mod, ldm, s.vt, D, nullptr, 0, 0.f));
+    }
+    VITA_TRY(vita_mse_loss_fwd_f32(s.vt, s.ut, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_FLOW, st));
+    if (nce_enc) VITA_TRY(nce_forward(s.z0, D, z1, D, B, D, tau, losses + VITA_LOSS_ENC_CONTRASTIVE, s.nce_enc, st));              // :134-139
+    // Euler sampler with grad, vita_policy.py:153-160 / flow_matchers.py:55-79
+    if (do_sample) {
+        for (int k = 1; k < K; ++k) {
             const int e = k + 1;
             float* dst = (k == K - 1) ? pred : fc.X(e + 1);
-            VITA_TRY(flow_eval_fwd(fc, e, s.flow.mod + (size_t)(B + k) * ldm, 0, dst, D, fc.X(e), D, dt));
+            VITA_TRY(flow_eval_fwd(fc, e, step_mod(k), 0, dst, D, fc.X(e), D, dt));
         }
         if (do_cons) VITA_TRY(vita_mse_loss_fwd_f32(pred, z1, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_CONSISTENCY, st));   // :162-165
         if (nce_flow) VITA_TRY(nce_forward(s.z0, D, pred, D, B, D, tau, losses + VITA_LOSS_FLOW_CONTRASTIVE, s.nce_flow, st));   // :167-172
@@ -681,19 +715,23 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     if (nce_enc) VITA_TRY(nce_backward(B, D, tau, s.consts + 4, s.dz0c, D, nce_flow ? 1 : 0, dz1, D, 1, s.nce_enc, st));
     // flow-matching evaluation
     VITA_TRY(vita_mse_loss_bwd_f32(s.vt, s.ut, (int64_t)B * D, s.consts + 0, fc.DV(0), s.dut, 0, st));
-    VITA_TRY(flow_eval_bwd(fc, 0, s.flow.mod, ldm, s.flow.dmod, s.dxt, D, nullptr, 0));
-    // Euler steps, last to first: dx_k = dx_{k+1} + J_k^T (dt * dx_{k+1})
+    // Euler steps, last to first: dx_k = dx_{k+1} + J_k^T (dt * dx_{k+1}); step 0 shares its pass with the flow-matching rows
     if (do_sample) {
         const float* dxn = dpred;
-        for (int k = K - 1; k >= 0; --k) {
+        for (int k = K - 1; k >= 1; --k) {
             const int e = k + 1;
             VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, dt, fc.DV(e), nullptr, 0, B, D, st));
-            float* dst = (k == 0) ? s.dz0 : ((k & 1) ? s.dxa : s.dxb);
-            VITA_TRY(flow_eval_bwd(fc, e, s.flow.mod + (size_t)(B + k) * ldm, 0, s.flow.DM, dst, D, dxn, D));
-            if (L > 0) VITA_TRY(vita_colsum_f32(s.flow.DM, ldm, B, L * 3 * H, s.cs_part, s.flow.dmod + (size_t)(B + k) * ldm, 0, st));
+            float* dst = (k & 1) ? s.dxa : s.dxb;
+            VITA_TRY(flow_eval_bwd(fc, e, step_mod(k), 0, s.flow.DM, dst, D, dxn, D));
+            if (L > 0) VITA_TRY(vita_colsum_f32(s.flow.DM, ldm, B, L * 3 * H, s.cs_part, s.flow.dmod + (size_t)(2 * B - 1 + k) * ldm, 0, st));
             dxn = dst;
         }
+        VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, dt, fc.DV(1), nullptr, 0, B, D, st));
+        VITA_TRY(flow_chain_bwd(fc, 0, 2 * B, s.flow.mod, ldm, s.flow.dmod));   // per-row modulation gradients: table rows 0..2B-1
+        VITA_TRY(flow_in_bwd(fc, 0, s.dxt, D, nullptr, 0));
+        VITA_TRY(flow_in_bwd(fc, 1, s.dz0, D, dxn, D));
     } else {
+        VITA_TRY(flow_eval_bwd(fc, 0, s.flow.mod, ldm, s.flow.dmod, s.dxt, D, nullptr, 0));
         VITA_CHECK_HIP(hipMemsetAsync(s.dz0, 0, (size_t)B * D * 4, st));
     }
     if (plain_cfm) VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
