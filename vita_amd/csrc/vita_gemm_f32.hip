@@ -302,6 +302,9 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk, const EpiFold* fold = nullptr);
 int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
+int gemm_f32_t_check(const vita_linear_args& a);
+int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
+bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws);
 bool gemm_f32_dma_eligible(const vita_linear_args& a);
 
 // ---- split-K: second pass ------------------------------------------------------------------------
@@ -438,6 +441,34 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
     return VITA_OK;
 }
 
+// Few-row GEMMs (vita_gemm_f32_small.hip): the in-workgroup reduction covers K <= 1024; longer reductions are split over
+// workgroups (<= 512 k each, at most 8 splits) and finished by the deterministic second pass.
+static int run_small(const vita_linear_args& a, hipStream_t stream) {
+    SplitK sk;
+    if (a.K > 1024) {
+        int S = (a.K + 511) / 512;
+        if (S > 8) S = 8;
+        const int64_t ldp = ((int64_t)a.N + 3) & ~int64_t(3);
+        const long by_ws = (long)(a.splitk_ws_bytes / ((size_t)a.M * ldp * sizeof(float)));
+        if (S > by_ws) S = (int)by_ws;
+        if (S >= 2) {
+            int kps = ((a.K + S - 1) / S + 7) & ~7;
+            sk.splits = (a.K + kps - 1) / kps;
+            sk.k_per_split = kps;
+            sk.partial = static_cast<float*>(a.splitk_ws);
+            sk.ld_partial = ldp;
+            if (sk.splits < 2) sk.splits = 1;
+        }
+    }
+    VITA_TRY_RC(gemm_f32_small(a, stream, sk.splits > 1 ? &sk : nullptr));
+    if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
+    return VITA_OK;
+}
+static bool small_ws_ok(const vita_linear_args& a) {
+    return a.splitk_ws != nullptr && (reinterpret_cast<uintptr_t>(a.splitk_ws) & 255u) == 0 &&
+           a.splitk_ws_bytes >= (size_t)2 * a.M * (((size_t)a.N + 3) & ~size_t(3)) * sizeof(float);
+}
+
 int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t stream) {
     VITA_REQUIRE(a.X && a.W && a.Y && !a.a_col && !a.b_col && a.pro == VITA_PRO_NONE && a.preact == nullptr && a.act_grad_z == nullptr &&
                      gemm_f32_dma_eligible(a),
@@ -454,6 +485,10 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
         if (taken) return VITA_OK;
     }
     if (a.a_col || a.b_col) {
+        if (!a.a_col && gemm_f32_small_eligible(a, small_ws_ok(a))) {
+            VITA_TRY_RC(gemm_f32_t_check(a));
+            return run_small(a, stream);
+        }
         const SplitK sk = (a.M > 0 && a.K > 0) ? plan_splitk(a) : SplitK{};
         VITA_TRY_RC(gemm_f32_t(a, stream, sk.splits > 1 ? &sk : nullptr));
         if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
@@ -476,6 +511,7 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
     VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "vita_linear_f32: ld_resid must be >= N");
     VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W,
                  "vita_linear_f32: Y must not alias X or W");
+    if (gemm_f32_small_eligible(a, small_ws_ok(a))) return run_small(a, stream);
     if (gemm_f32_dma_eligible(a)) {
         const SplitK sk = plan_splitk(a);
         VITA_TRY_RC(gemm_f32_dma(a, stream, sk.splits > 1 ? &sk : nullptr));

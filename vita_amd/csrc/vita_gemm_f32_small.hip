@@ -1,0 +1,186 @@
+// fp32 MFMA GEMM for few-row problems (M <= 512: the B = 128 training step, serving batches, the time path).
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) ),   A(m,k) = X[m*ldx + k],   B(n,k) = W[n*ldw + k]  (b_col: W[k*ldw + n])
+//
+// At these sizes the LDS-DMA kernel's fixed cost (three-stage prologue, LDS-transposing epilogue: ~20 k cycles) is most of
+// its run time, and filling the chip needs a split-K second pass.  Here one workgroup owns a 32 x 32 output tile and its NW
+// waves split the reduction: wave w reduces k in [w*kw, (w+1)*kw) with operands loaded global -> VGPR directly in MFMA
+// fragment layout (lane = row | 32*half reads the 16 bytes k = 8c + 4*half .. +3 of its row: the k pairing of the other
+// kernels), every load of a batch of chunks issued before the first MFMA; the NW partial tiles are summed through LDS in
+// wave order (deterministic) and 256 threads apply the epilogue on row-major float4s.  No LDS staging, no pipeline, and the
+// in-workgroup reduction replaces the split-K pass for K <= 1024 (above that a grid-level split feeds the usual
+// splitk_reduce_kernel).  A column operand (dgrad: B(n,k) = W[k][n]) is read with four coalesced dword loads per chunk.
+#include "vita_gemm_epilogue.h"
+
+namespace vita {
+
+struct SmallParams {
+    const float* X; int64_t ldx;
+    const float* W; int64_t ldw;
+    int M, N, K;
+    int tiles_n;
+    int kw;                  // k elements per wave (multiple of 8)
+    int sk_splits, sk_k;     // grid-level split-K (k elements per split, multiple of 8)
+    EpiParams epi;
+};
+
+constexpr int SM_TS = 36;    // LDS row stride of a partial tile (floats): 16-byte aligned rows
+
+template <bool BCOL, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) {
+    constexpr int CB = 16;   // chunks (of 8 k) loaded per batch
+    __shared__ __attribute__((aligned(16))) float red[NW * 32 * SM_TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ntile = p.tiles_n * ((p.M + 31) / 32);
+    const int split = p.sk_splits > 1 ? (int)blockIdx.x / ntile : 0;
+    const int bid = (int)blockIdx.x - split * ntile;
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int kbase = split * p.sk_k;
+    const int Kend = p.sk_splits > 1 ? min(p.K, kbase + p.sk_k) : p.K;
+    const int k0 = kbase + wave * p.kw;
+    const int k1 = min(Kend, k0 + p.kw);
+    const int nch = k1 > k0 ? (k1 - k0 + 7) / 8 : 0;
+
+    const float* arow = p.X + (int64_t)min(m0 + fr, p.M - 1) * p.ldx;
+    const int ncol = min(n0 + fr, p.N - 1);
+    const float* brow = BCOL ? p.W + ncol : p.W + (int64_t)ncol * p.ldw;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int c0 = 0; c0 < nch; c0 += CB) {
+        f32x4 a[CB], b[CB];
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            const int kk = k0 + (c0 + c) * 8 + fh * 4;
+            const bool ok = (c0 + c) < nch && kk < k1;       // K % 4 == 0 and kk % 4 == 0: the four k exist together
+            a[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok) {
+                a[c] = *reinterpret_cast<const f32x4*>(arow + kk);
+                if constexpr (BCOL) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) b[c][e] = brow[(int64_t)(kk + e) * p.ldw];
+                } else {
+                    b[c] = *reinterpret_cast<const f32x4*>(brow + kk);
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CB; ++c) {
+            if (c0 + c < nch) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[c][e], b[c][e], acc, 0, 0, 0);
+            }
+        }
+    }
+
+    // partial tile of this wave -> LDS (accumulator register r of a lane: row (r&3) + 8*(r>>2) + 4*half, column lane&31)
+    float* mine = red + wave * (32 * SM_TS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * SM_TS + fr] = acc[r];
+    __syncthreads();
+    if (tid >= 256) return;
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(red + lr * SM_TS + lc);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * (32 * SM_TS) + lr * SM_TS + lc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += t[k];
+    }
+    const EpiParams& e = p.epi;
+    const int row = m0 + lr, col = n0 + lc;
+    if (row >= e.M || col >= e.N) return;
+    if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
+        float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
+        if (col + 3 < e.N) *reinterpret_cast<f32x4*>(dst) = s;
+        else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
+        return;
+    }
+    const bool bwd = e.act_grad_z != nullptr;
+    const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
+    const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
+    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
+    if (e.vec && col + 3 < e.N) {
+        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, zin = bias, g = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar}, rs = bias, pre, out;
+        if (e.bias) bias = *reinterpret_cast<const f32x4*>(e.bias + col);
+        if (bwd) zin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+        if (gate_vec) g = *reinterpret_cast<const f32x4*>(e.gate + col);
+        else if (gate_mat) g = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
+        if (e.resid) rs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z = s[k] + bias[k];
+            pre[k] = z;
+            float v = bwd ? z * act_grad(zin[k], e.act) : apply_act(z, e.act);
+            if (has_gate) v = v * g[k];
+            if (e.resid) v = rs[k] + v;
+            out[k] = v;
+        }
+        if (e.preact) *reinterpret_cast<f32x4*>(e.preact + (int64_t)row * e.ld_preact + col) = pre;
+        *reinterpret_cast<f32x4*>(e.Y + (int64_t)row * e.ldy + col) = out;
+    } else {
+        for (int k = 0; k < 4 && col + k < e.N; ++k) {
+            const int cc = col + k;
+            const float z = s[k] + (e.bias ? e.bias[cc] : 0.f);
+            if (e.preact) e.preact[(int64_t)row * e.ld_preact + cc] = z;
+            float v = bwd ? z * act_grad(e.act_grad_z[(int64_t)row * e.ld_act_grad_z + cc], e.act) : apply_act(z, e.act);
+            const float g = gate_vec ? e.gate[cc] : (gate_mat ? e.gate[(int64_t)row * e.ld_gate + cc] : e.gate_scalar);
+            if (has_gate) v = v * g;
+            if (e.resid) v = e.resid[(int64_t)row * e.ld_resid + cc] + v;
+            e.Y[(int64_t)row * e.ldy + cc] = v;
+        }
+    }
+}
+
+// Shapes this kernel is meant for.  k_split = 0: the caller has no split-K scratch.
+bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws) {
+#ifdef VITA_NO_SMALL_GEMM
+    return false;
+#endif
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (a.a_col || a.pro != VITA_PRO_NONE || a.M <= 0 || a.M > 512 || a.N < 32 || a.K < 64) return false;
+    if (a.K % 4 != 0 || a.ldx % 4 != 0 || !al(a.X)) return false;
+    if (!a.b_col && (a.ldw % 4 != 0 || !al(a.W))) return false;
+    // one 32 x 32 tile per workgroup re-reads operands (M/32 + N/32) times: keep the L2 traffic of a launch bounded
+    const double traffic = ((double)((a.M + 31) / 32) * a.N + (double)((a.N + 31) / 32) * a.M) * a.K * 4.0;
+    if (traffic > 96e6) return false;
+    if (a.K > 1024 && !have_splitk_ws) return false;
+    return true;
+}
+
+// sk: grid-level split (k_per_split multiple of 8) or NULL.
+int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) {
+    SmallParams p{};
+    p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.M = a.M; p.N = a.N; p.K = a.K;
+    p.tiles_n = (a.N + 31) / 32;
+    EpiParams& e = p.epi;
+    e.Y = a.Y; e.ldy = a.ldy; e.M = a.M; e.N = a.N; e.bias = a.bias; e.act = a.act;
+    e.gate = a.gate; e.ld_gate = a.ld_gate; e.use_gate_scalar = a.use_gate_scalar; e.gate_scalar = a.use_gate_scalar ? a.gate_scalar : 1.0f;
+    e.resid = a.resid; e.ld_resid = a.ld_resid; e.preact = a.preact; e.ld_preact = a.ld_preact;
+    e.act_grad_z = a.act_grad_z; e.ld_act_grad_z = a.ld_act_grad_z;
+    e.vec = epi_vec_ok(e);
+    int kspan = a.K;
+    if (sk && sk->splits > 1) {
+        p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; e.partial = sk->partial; e.ld_partial = sk->ld_partial;
+        kspan = sk->k_per_split;
+    }
+    const int nw = kspan <= 512 ? 4 : 8;
+    p.kw = ((kspan + nw - 1) / nw + 7) & ~7;
+    const unsigned grid = (unsigned)(p.tiles_n * ((a.M + 31) / 32) * (p.sk_splits > 1 ? p.sk_splits : 1));
+    if (a.b_col) {
+        if (nw == 4) hipLaunchKernelGGL((gemm_f32_small_kernel<true, 4>), dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_small_kernel<true, 8>), dim3(grid), dim3(512), 0, stream, p);
+    } else {
+        if (nw == 4) hipLaunchKernelGGL((gemm_f32_small_kernel<false, 4>), dim3(grid), dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_small_kernel<false, 8>), dim3(grid), dim3(512), 0, stream, p);
+    }
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+}  // namespace vita

@@ -209,7 +209,7 @@ static int launch_t(GemmParamsT p, bool vec, hipStream_t stream) {
     return VITA_OK;
 }
 
-int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) {
+int gemm_f32_t_check(const vita_linear_args& a) {
     const char* who = "vita_linear_f32 (transposed operands)";
     VITA_REQUIRE(a.X && a.W && a.Y, "%s: X, W and Y must be non-null", who);
     VITA_REQUIRE(a.M > 0 && a.N > 0 && a.K >= 0, "%s: bad shape M=%d N=%d K=%d", who, a.M, a.N, a.K);
@@ -221,6 +221,15 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) 
     VITA_REQUIRE(a.act_grad_z == nullptr || a.ld_act_grad_z >= a.N, "%s: ld_act_grad_z must be >= N", who);
     VITA_REQUIRE(a.resid == nullptr || a.ld_resid >= a.N, "%s: ld_resid must be >= N", who);
     VITA_REQUIRE((const void*)a.Y != (const void*)a.X && (const void*)a.Y != (const void*)a.W, "%s: Y must not alias X or W", who);
+    return VITA_OK;
+}
+
+int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) {
+    const char* who = "vita_linear_f32 (transposed operands)";
+    {
+        const int rc = gemm_f32_t_check(a);
+        if (rc != VITA_OK) return rc;
+    }
     if (a.K == 0 && a.resid == nullptr) {   // empty reduction: the result is the bias (wgrad of an empty batch is zero)
         VITA_REQUIRE(a.bias == nullptr, "%s: K == 0 with a bias is not supported", who);
         VITA_CHECK_HIP(hipMemset2DAsync(a.Y, (size_t)a.ldy * 4, 0, (size_t)a.N * 4, (size_t)a.M, stream));
