@@ -324,9 +324,12 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
 #ifndef VITA_LN_ROWS
 #define VITA_LN_ROWS 4
 #endif
-    if (H <= 256) VITA_LN(1, VITA_LN_ROWS);
-    else if (H <= 512) VITA_LN(2, VITA_LN_ROWS);
-    else if (H <= 1024) VITA_LN(4, 2);
+    // few rows: one row per wave (a wave's rows share its shuffle chains: 4 rows = 48 dependent cross-lane steps, which is
+    // what a launch at M <= 1024 spends its time on); many rows: several rows in flight per wave to cover the memory latency
+    const bool few = M <= 1024;
+    if (H <= 256) { if (few) VITA_LN(1, 1); else VITA_LN(1, VITA_LN_ROWS); }
+    else if (H <= 512) { if (few) VITA_LN(2, 1); else VITA_LN(2, VITA_LN_ROWS); }
+    else if (H <= 1024) { if (few) VITA_LN(4, 1); else VITA_LN(4, 2); }
     else VITA_LN(8, 1);
 #undef VITA_LN
     VITA_CHECK_HIP(hipGetLastError());

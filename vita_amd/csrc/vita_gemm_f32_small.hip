@@ -51,6 +51,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+    // epilogue operands of this thread's output float4, requested before the reduction so their latency hides behind it
+    const int lr = (tid & 255) >> 3, lc = (tid & 7) * 4;
+    const int row = m0 + lr, col = n0 + lc;
+    const EpiParams& e = p.epi;
+    const bool bwd = e.act_grad_z != nullptr;
+    const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
+    const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
+    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
+    const bool fast = tid < 256 && e.partial == nullptr && e.vec && row < e.M && col + 3 < e.N;
+    f32x4 pbias = {0.f, 0.f, 0.f, 0.f}, pzin = pbias, prs = pbias, pg = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
+    if (fast) {
+        if (e.bias) pbias = *reinterpret_cast<const f32x4*>(e.bias + col);
+        if (bwd) pzin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+        if (gate_vec) pg = *reinterpret_cast<const f32x4*>(e.gate + col);
+        else if (gate_mat) pg = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
+        if (e.resid) prs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+    }
+
     for (int c0 = 0; c0 < nch; c0 += CB) {
         f32x4 a[CB], b[CB];
 #pragma unroll
@@ -84,7 +102,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
     for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * SM_TS + fr] = acc[r];
     __syncthreads();
     if (tid >= 256) return;
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
     f32x4 s = *reinterpret_cast<const f32x4*>(red + lr * SM_TS + lc);
 #pragma unroll
     for (int w = 1; w < NW; ++w) {
@@ -92,8 +109,6 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] += t[k];
     }
-    const EpiParams& e = p.epi;
-    const int row = m0 + lr, col = n0 + lc;
     if (row >= e.M || col >= e.N) return;
     if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
         float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
@@ -101,17 +116,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
         else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
         return;
     }
-    const bool bwd = e.act_grad_z != nullptr;
-    const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
-    const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
-    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
-    if (e.vec && col + 3 < e.N) {
-        f32x4 bias = {0.f, 0.f, 0.f, 0.f}, zin = bias, g = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar}, rs = bias, pre, out;
-        if (e.bias) bias = *reinterpret_cast<const f32x4*>(e.bias + col);
-        if (bwd) zin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
-        if (gate_vec) g = *reinterpret_cast<const f32x4*>(e.gate + col);
-        else if (gate_mat) g = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
-        if (e.resid) rs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+    if (fast) {
+        const f32x4 bias = pbias, zin = pzin, g = pg, rs = prs;
+        f32x4 pre, out;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const float z = s[k] + bias[k];
