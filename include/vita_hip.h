@@ -327,6 +327,12 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
                                       tests/test_gpu_bf16_train.py (BASELINE configs[2]) */
     int32_t fm_kind;               /* VITA_FM_*: flow_matcher.name conditional / exact (0), target (1), schrodinger (2) */
     float fm_sigma;                /* flow_matcher.sigma (vita.yaml:24: 0.0); > 0 or kinds 1 / 2 need `fm_noise` */
+    int32_t side_streams;          /* 0 (default): everything on `stream`.  1: with grads, B <= 1024 and fp32 GEMMs the decoder's weight
+                                      gradients, the time path's and the encoders' backward are enqueued on three library-owned
+                                      non-blocking side streams (created on a host thread's first such call on a device and kept),
+                                      forked from and joined back into `stream` with events; grad_ready[0] is then recorded on a side
+                                      stream.  Same bits as the single-stream order.  Measured on MI355X: the branches do not overlap
+                                      the main chain's small kernels (B=128 step 3.34 -> 3.44 ms), hence off by default */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,

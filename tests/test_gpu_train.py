@@ -366,3 +366,29 @@ def test_compute_loss_rejects_bad_arguments(ops, dev, tiny):
         ops.compute_loss(pw, ops.loss_config(6), obs, acts[:, :8], t)
     with pytest.raises(ValueError):
         ops.loss_config(6, recon="huber")
+
+
+def test_side_stream_branches_match_the_single_stream_step_bitwise(ops, dev):
+    """side_streams=True (opt-in), B <= 1024: decoder weight gradients / time-path backward / encoder backward run on
+    library-owned side streams.  The same kernels on the same data must give the same bits as the single-stream order, call
+    after call (a race would not)."""
+    O_, A, T, B = 533, 21, 16, 128
+    sd = O.make_state_dict(O_, A, seed=0)
+    g = torch.Generator().manual_seed(33)
+    obs, actions, t = torch.randn(B, O_, generator=g), torch.randn(B, T, A, generator=g), torch.rand(B, generator=g)
+    l0, g0, d0 = run_fused(ops, dev, sd, obs, actions, t, ops.loss_config(num_steps=6))
+    for rep in range(4):
+        l1, g1, d1 = run_fused(ops, dev, sd, obs, actions, t, ops.loss_config(num_steps=6, side_streams=True))
+        assert torch.equal(l0, l1) and torch.equal(d0, d1), rep
+        bad = [k for k in sd if not torch.equal(g0[k], g1[k])]
+        assert not bad, (rep, bad)
+    # also on a non-default stream, with the simple encoder and the contrastive terms
+    sd2 = O.make_state_dict(40, 7, latent_dim=64, hidden_dim=64, num_layers=3, pred_horizon=T, ae_hidden=48, ae_layers=2, time_embed_dim=32,
+                            seed=5, encoder_type="simple")
+    obs2, act2, t2 = torch.randn(19, 40, generator=g), torch.randn(19, T, 7, generator=g), torch.rand(19, generator=g)
+    kw = dict(num_steps=6, enc_contrastive_weight=0.3, flow_contrastive_weight=0.2)
+    l0, g0, _ = run_fused(ops, dev, sd2, obs2, act2, t2, ops.loss_config(**kw))
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        l1, g1, _ = run_fused(ops, dev, sd2, obs2, act2, t2, ops.loss_config(side_streams=True, **kw))
+    assert torch.equal(l0, l1) and all(torch.equal(g0[k], g1[k]) for k in sd2)

@@ -30,6 +30,8 @@ batch = {cfg.task.state_key: torch.randn(B, 1, S, generator=g).to(dev),
          cfg.task.action_key: torch.randn(B, 16, A, generator=g).to(dev)}
 tts = torch.rand(64, B, generator=g).to(dev)
 tr.step_counter = 1000
+if os.environ.get("VITA_PROFILE_STREAM"):      # run the step on a non-default torch stream
+    torch.cuda.set_stream(torch.cuda.Stream(device=dev))
 for i in range(3):
     tr.train_step(batch, t=tts[i % 64])
 torch.cuda.synchronize()
@@ -39,3 +41,10 @@ for i in range(steps):
 torch.cuda.synchronize()
 el = time.perf_counter() - t0
 print(f"B={B} steps={steps} ms_per_step={el * 1e3 / steps:.3f} samples_per_s={B * steps / el:.1f} loss={tr.metrics()['loss']:.6f}")
+# host-side enqueue time of one step (GPU idle at the start): if it is close to ms_per_step the step is launch-rate bound
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+tr.train_step(batch, t=tts[0])
+host = time.perf_counter() - t0
+torch.cuda.synchronize()
+print(f"host enqueue time of one step: {host * 1e3:.3f} ms")

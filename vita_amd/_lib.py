@@ -103,7 +103,7 @@ class LossConfig(C.Structure):
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
         ("kl_weight", C.c_float), ("gemm_bf16", C.c_int32),
-        ("fm_kind", C.c_int32), ("fm_sigma", C.c_float),
+        ("fm_kind", C.c_int32), ("fm_sigma", C.c_float), ("side_streams", C.c_int32),
     ]
 
 

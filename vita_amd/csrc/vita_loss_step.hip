@@ -40,7 +40,7 @@ struct StackWs {
     float *G = nullptr;    // (NL, M, FF) gelu(P)
     float *out = nullptr;  // (M, OUT)
     float *dOut = nullptr; // (M, OUT)
-    float *s1 = nullptr, *s2 = nullptr;  // (M, TR) gradient ping-pong
+    float *dA[VITA_MAX_LAYERS + 1] = {};  // (M, TR) gradient of trunk activation i, i = 0..NL: each kept until its wgrad has run
 };
 Stack stack_of(const vita_decoder_weights& w) {
     Stack s;
@@ -64,8 +64,7 @@ StackWs carve_stack(Carver& c, const Stack& s, size_t M, bool train) {
     if (s.OUT) w.out = c.take(M * s.OUT);
     if (train) {
         if (s.OUT) w.dOut = c.take(M * s.OUT);
-        w.s1 = c.take(M * s.TR);
-        w.s2 = c.take(M * s.TR);
+        for (int i = 0; i <= s.NL; ++i) w.dA[i] = c.take(M * s.TR);
     }
     return w;
 }
@@ -83,42 +82,57 @@ int stack_fwd(const Stack& s, const StackWs& w, const float* x, int64_t ldx, int
     if (s.OUT) VITA_TRY(gemm_f32(lin(trunk(s.NL), s.TR, s.out_w, s.TR, s.out_b, w.out, s.OUT, M, s.OUT, s.TR, VITA_ACT_NONE), st));
     return VITA_OK;
 }
-inline float* mut(const float* p) { return const_cast<float*>(p); }
-
-// d_top: gradient of the stack's result — (M, OUT) w.dOut when OUT > 0, else the gradient of A[NL] (M, TR).
-// g: gradient buffers in the same descriptor.  dx: NULL or (M, IN) receiving the input gradient.
-int stack_bwd(const Stack& s, const Stack& g, const StackWs& w, const float* x, int64_t ldx, int M, const float* last_trunk,
-              const float* d_top, int64_t ld_top, float* dx, int64_t ld_dx, float* cs_part, hipStream_t st) {
-    const size_t tr = (size_t)M * s.TR, ff = (size_t)M * s.FF;
-    auto trunk = [&](int i) -> const float* { return (i == s.NL && last_trunk) ? last_trunk : w.A + (size_t)i * tr; };
+// Backward of the stack in two parts so that a caller may run them on different streams: the input-gradient chain
+// (stack_chain_bwd: what the rest of the backward pass waits for) and the weight / bias gradients (stack_wgrads: needs only
+// what the chain left behind).  d_top: gradient of the stack's result — (M, OUT) w.dOut when OUT > 0, else the gradient of
+// A[NL] (M, TR).  dx: NULL or (M, IN) receiving the input gradient.  The chain leaves d A[i] in w.dA[i] (i < NL; i = NL
+// too when OUT > 0) and dP_i in place of the saved pre-activation P_i.
+int stack_chain_bwd(const Stack& s, const StackWs& w, int M, const float* d_top, int64_t ld_top, float* dx, int64_t ld_dx, hipStream_t st) {
+    const size_t ff = (size_t)M * s.FF;
     const float* dA = d_top;
     int64_t ld_dA = ld_top;
-    float* free_buf = w.s1;
-    float* other = w.s2;
     if (s.OUT) {
-        VITA_TRY(gemm_f32(wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT), st));
-        VITA_TRY(vita_colsum_f32(d_top, ld_top, M, s.OUT, cs_part, mut(g.out_b), 0, st));
-        VITA_TRY(gemm_f32(dgrad(d_top, ld_top, s.out_w, s.TR, free_buf, s.TR, M, s.TR, s.OUT), st));
-        dA = free_buf; ld_dA = s.TR;
-        float* tmp = free_buf; free_buf = other; other = tmp;
+        VITA_TRY(gemm_f32(dgrad(d_top, ld_top, s.out_w, s.TR, w.dA[s.NL], s.TR, M, s.TR, s.OUT), st));
+        dA = w.dA[s.NL]; ld_dA = s.TR;
     }
     for (int i = s.NL - 1; i >= 0; --i) {
         float* P = w.P + i * ff;
-        VITA_TRY(gemm_f32(wgrad(dA, ld_dA, w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
-        VITA_TRY(vita_colsum_f32(dA, ld_dA, M, s.TR, cs_part, mut(g.fc2_b[i]), 0, st));
         vita_linear_args a = dgrad(dA, ld_dA, s.fc2_w[i], s.FF, P, s.FF, M, s.FF, s.TR);   // dP = (dA . W2) * gelu'(P), in place
         a.act = VITA_ACT_GELU_ERF; a.act_grad_z = P; a.ld_act_grad_z = s.FF;
         VITA_TRY(gemm_f32(a, st));
-        VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
-        VITA_TRY(vita_colsum_f32(P, s.FF, M, s.FF, cs_part, mut(g.fc1_b[i]), 0, st));
-        VITA_TRY(gemm_f32(dgrad(P, s.FF, s.fc1_w[i], s.TR, free_buf, s.TR, M, s.TR, s.FF), st));
-        dA = free_buf; ld_dA = s.TR;
-        float* tmp = free_buf; free_buf = other; other = tmp;
+        VITA_TRY(gemm_f32(dgrad(P, s.FF, s.fc1_w[i], s.TR, w.dA[i], s.TR, M, s.TR, s.FF), st));
+        dA = w.dA[i]; ld_dA = s.TR;
     }
-    VITA_TRY(gemm_f32(wgrad(dA, ld_dA, x, ldx, mut(g.in_w), s.IN, M, s.IN, s.TR), st));
-    VITA_TRY(vita_colsum_f32(dA, ld_dA, M, s.TR, cs_part, mut(g.in_b), 0, st));
     if (dx) VITA_TRY(gemm_f32(dgrad(dA, ld_dA, s.in_w, s.IN, dx, ld_dx, M, s.IN, s.TR), st));
     return VITA_OK;
+}
+inline float* mut(const float* p) { return const_cast<float*>(p); }
+// g: gradient buffers in the same descriptor; x: the stack's input rows; last_trunk as in stack_fwd.
+int stack_wgrads(const Stack& s, const Stack& g, const StackWs& w, const float* x, int64_t ldx, int M, const float* last_trunk,
+                 const float* d_top, int64_t ld_top, float* cs_part, hipStream_t st) {
+    const size_t tr = (size_t)M * s.TR, ff = (size_t)M * s.FF;
+    auto trunk = [&](int i) -> const float* { return (i == s.NL && last_trunk) ? last_trunk : w.A + (size_t)i * tr; };
+    auto dA = [&](int i) -> const float* { return (i == s.NL && !s.OUT) ? d_top : w.dA[i]; };
+    auto ld_dA = [&](int i) -> int64_t { return (i == s.NL && !s.OUT) ? ld_top : s.TR; };
+    if (s.OUT) {
+        VITA_TRY(gemm_f32(wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT), st));
+        VITA_TRY(vita_colsum_f32(d_top, ld_top, M, s.OUT, cs_part, mut(g.out_b), 0, st));
+    }
+    for (int i = s.NL - 1; i >= 0; --i) {
+        const float* P = w.P + i * ff;
+        VITA_TRY(gemm_f32(wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
+        VITA_TRY(vita_colsum_f32(dA(i + 1), ld_dA(i + 1), M, s.TR, cs_part, mut(g.fc2_b[i]), 0, st));
+        VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
+        VITA_TRY(vita_colsum_f32(P, s.FF, M, s.FF, cs_part, mut(g.fc1_b[i]), 0, st));
+    }
+    VITA_TRY(gemm_f32(wgrad(dA(0), ld_dA(0), x, ldx, mut(g.in_w), s.IN, M, s.IN, s.TR), st));
+    VITA_TRY(vita_colsum_f32(dA(0), ld_dA(0), M, s.TR, cs_part, mut(g.in_b), 0, st));
+    return VITA_OK;
+}
+int stack_bwd(const Stack& s, const Stack& g, const StackWs& w, const float* x, int64_t ldx, int M, const float* last_trunk,
+              const float* d_top, int64_t ld_top, float* dx, int64_t ld_dx, float* cs_part, hipStream_t st) {
+    VITA_TRY(stack_chain_bwd(s, w, M, d_top, ld_top, dx, ld_dx, st));
+    return stack_wgrads(s, g, w, x, ldx, M, last_trunk, d_top, ld_top, cs_part, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -399,10 +413,47 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
 }
 
 // ------------------------------------------------------------------------------------------------
+// Side streams for the launch-bound regime (B <= 1024), opt-in (vita_loss_config.side_streams).  The backward pass has three pieces that nothing later in the
+// step waits for — the decoder's weight gradients (ready once its input-gradient chain has run, while the K sampler steps
+// are still to be unrolled), the time path's backward and the encoders' backward (both independent of the flow net's
+// stacked weight gradients) — and at these sizes every kernel leaves most of the chip idle.  They are enqueued on three
+// non-blocking side streams between a fork event recorded on the caller's stream and join events the caller's stream
+// waits for before the call returns its last event, each branch with its own split-K and column-sum scratch.
+// The streams and events are created on the first such call of a host thread on a device and kept (the only objects this
+// library ever creates); the fork / join pattern is the one HIP graph capture records as parallel branches.
+// Measured (rocprofv3 kernel trace, profiles/): the branches' kernels do not overlap the main chain's on this runtime —
+// the caller's stream stalls while a side queue drains — so the B = 128 step does not get shorter (3.34 -> 3.44 ms) and
+// the default stays single-stream.  The split of the stack's backward into chain + weight gradients is kept either way.
+// ------------------------------------------------------------------------------------------------
+struct Side {
+    hipStream_t s[3] = {};
+    hipEvent_t fork[2] = {}, join[3] = {};
+    bool init = false, ok = false;
+};
+Side* side_for_current_device() {
+    static thread_local Side sides[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+    Side& sd = sides[dev];
+    if (!sd.init) {
+        sd.init = true;
+        bool ok = true;
+        for (int i = 0; i < 3 && ok; ++i) ok = hipStreamCreateWithFlags(&sd.s[i], hipStreamNonBlocking) == hipSuccess;
+        for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&sd.fork[i], hipEventDisableTiming) == hipSuccess;
+        for (int i = 0; i < 3 && ok; ++i) ok = hipEventCreateWithFlags(&sd.join[i], hipEventDisableTiming) == hipSuccess;
+        sd.ok = ok;
+        if (!ok) (void)hipGetLastError();
+    }
+    return sd.ok ? &sd : nullptr;
+}
+constexpr int kSideMaxRows = 1024;
+
+// ------------------------------------------------------------------------------------------------
 // whole-step workspace
 // ------------------------------------------------------------------------------------------------
 struct StepWs {
     float *sk, *consts, *loss_part, *cs_part;
+    float *sk_side[3], *cs_side[3];   // split-K / column-sum scratch of the side-stream branches
     float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
     float *ut, *vt, *dut, *dxt, *dxa, *dxb;
     float *params, *dparams, *kl_rows;  // variational encoder: [mean | logvar] rows (B, 2D), their gradient, per-row KL
@@ -452,6 +503,11 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     s.consts = c.take(16);
     s.loss_part = c.take((size_t)vita_loss_partials_count());
     s.cs_part = c.take((size_t)vita_colsum_partials_count(max_colsum_n(w)));
+    for (int i = 0; i < 3; ++i) {
+        const bool side = train && B <= (size_t)kSideMaxRows;
+        s.sk_side[i] = side ? c.take(kSplitkBytes / sizeof(float)) : nullptr;
+        s.cs_side[i] = side ? c.take((size_t)vita_colsum_partials_count(max_colsum_n(w))) : nullptr;
+    }
     s.z0 = c.take(B * D);
     s.ZZ = c.take(2 * B * D);
     s.ut = c.take(B * D);
@@ -603,6 +659,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     FlowCtx fc{&w->flow, s.flow, B, K, 1 + K, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
     Bf16Scope bfscope(s.stage, s.stage_bytes, cfg->gemm_bf16);
+    // the bf16 staging region is reused call after call in stream order: one stream only in that mode
+    Side* side = (train && B <= kSideMaxRows && cfg->gemm_bf16 == 0 && cfg->side_streams != 0) ? side_for_current_device() : nullptr;
     const bool vae = w->enc.variational != 0;
     const bool do_kl = vae && !fe && !(fe && fd) && cfg->kl_weight > 0.f;                                               // :142-146
 
@@ -690,8 +748,19 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         if (dec_pred) VITA_TRY(recon_bwd(s.dec.out, actions, n_rec, s.consts + 2, s.dec.dOut, nullptr, 0, st));
         if (dec_enc)
             VITA_TRY(recon_bwd(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.consts + 3, s.dec.dOut + (size_t)enc_row * OUT, nullptr, 0, st));
-        VITA_TRY(stack_bwd(dec, stack_of(g.dec), s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, s.dec.dOut, OUT, s.dZZ + (size_t)r0 * D, D,
-                           s.cs_part, st));
+        VITA_TRY(stack_chain_bwd(dec, s.dec, M, s.dec.dOut, OUT, s.dZZ + (size_t)r0 * D, D, st));
+        if (side) {   // the decoder's weight gradients run beside the sampler's backward
+            VITA_CHECK_HIP(hipEventRecord(side->fork[0], st));
+            VITA_CHECK_HIP(hipStreamWaitEvent(side->s[0], side->fork[0], 0));
+            {
+                SplitkScope sc(s.sk_side[0], kSplitkBytes);
+                VITA_TRY(stack_wgrads(dec, stack_of(g.dec), s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, s.dec.dOut, OUT, s.cs_side[0], side->s[0]));
+            }
+            if (grad_ready && grad_ready[0]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)grad_ready[0], side->s[0]));
+            VITA_CHECK_HIP(hipEventRecord(side->join[0], side->s[0]));
+        } else {
+            VITA_TRY(stack_wgrads(dec, stack_of(g.dec), s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, s.dec.dOut, OUT, s.cs_part, st));
+        }
     } else {  // the decoder takes no part in the loss
         const Stack gd = stack_of(g.dec);
         VITA_CHECK_HIP(hipMemsetAsync(mut(gd.in_w), 0, (size_t)gd.TR * gd.IN * 4, st));
@@ -705,7 +774,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_w), 0, (size_t)gd.OUT * gd.TR * 4, st));
         VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_b), 0, (size_t)gd.OUT * 4, st));
     }
-    VITA_TRY(record(0));
+    const bool dec_on_side = side != nullptr && M > 0;
+    if (!dec_on_side) VITA_TRY(record(0));
     float* dpred = s.dZZ;
     float* dz1 = s.dZZ + (size_t)B * D;
     if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
@@ -737,25 +807,52 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     if (plain_cfm) VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
     else VITA_TRY(vita_fm_interpolate_bwd_f32(cfg->fm_kind, (double)cfg->fm_sigma, s.dxt, s.dut, t, pair_i, pair_j, s.dz0, dz1, B, D, 1, st));
     if (nce_enc || nce_flow) VITA_TRY(launch_axpy(s.dz0c, s.dz0, (int64_t)B * D, st));
-    VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
-    VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
-    VITA_TRY(record(1));
-    // encoders
-    if (fe) {   // :119 the action latents were computed without grad
-        VITA_TRY(zero_encoder_grads(g.enc, st));
-    } else if (w->enc.kind == VITA_ENC_SIMPLE) {
-        VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
-                           w->enc.C, nullptr, 0, s.cs_part, st));
-    } else if (vae) {
-        const float ks = (do_kl && enc_noise) ? cfg->kl_weight / (float)B : 0.f;
-        VITA_TRY(launch_gauss_sample_bwd(s.params, 2 * D, enc_noise, dz1, D, ks, s.dparams, 2 * D, B, D, st));
-        VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, s.dparams, 2 * D, B, s.cs_part, st));
+    // encoders (on their own stream when forking)
+    auto encoders_bwd = [&](float* cs, hipStream_t es) -> int {
+        if (fe) {   // :119 the action latents were computed without grad
+            VITA_TRY(zero_encoder_grads(g.enc, es));
+        } else if (w->enc.kind == VITA_ENC_SIMPLE) {
+            VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
+                               w->enc.C, nullptr, 0, cs, es));
+        } else if (vae) {
+            const float ks = (do_kl && enc_noise) ? cfg->kl_weight / (float)B : 0.f;
+            VITA_TRY(launch_gauss_sample_bwd(s.params, 2 * D, enc_noise, dz1, D, ks, s.dparams, 2 * D, B, D, es));
+            VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, s.dparams, 2 * D, B, cs, es));
+        } else {
+            VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, dz1, D, B, cs, es));
+        }
+        VITA_TRY(gemm_f32(wgrad(s.dz0, D, obs_features, ldobs, mut(g.obs_w), w->O, B, w->O, D), es));
+        VITA_TRY(vita_colsum_f32(s.dz0, D, B, D, cs, mut(g.obs_b), 0, es));
+        if (d_obs_features) VITA_TRY(gemm_f32(dgrad(s.dz0, D, w->obs_w, w->O, d_obs_features, ld_dobs, B, w->O, D), es));
+        return VITA_OK;
+    };
+    if (side) {
+        VITA_CHECK_HIP(hipEventRecord(side->fork[1], st));
+        VITA_CHECK_HIP(hipStreamWaitEvent(side->s[1], side->fork[1], 0));
+        VITA_CHECK_HIP(hipStreamWaitEvent(side->s[2], side->fork[1], 0));
+        {
+            SplitkScope sc(s.sk_side[1], kSplitkBytes);
+            FlowCtx fcb = fc;
+            fcb.st = side->s[1];
+            VITA_TRY(time_path_bwd(fcb, g.flow, T, s.cs_side[1]));
+            VITA_CHECK_HIP(hipEventRecord(side->join[1], side->s[1]));
+        }
+        {
+            SplitkScope sc(s.sk_side[2], kSplitkBytes);
+            VITA_TRY(encoders_bwd(s.cs_side[2], side->s[2]));
+            VITA_CHECK_HIP(hipEventRecord(side->join[2], side->s[2]));
+        }
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
+        VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
+        VITA_TRY(record(1));
+        VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[2], 0));
+        if (dec_on_side) VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[0], 0));
     } else {
-        VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, dz1, D, B, s.cs_part, st));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
+        VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
+        VITA_TRY(record(1));
+        VITA_TRY(encoders_bwd(s.cs_part, st));
     }
-    VITA_TRY(gemm_f32(wgrad(s.dz0, D, obs_features, ldobs, mut(g.obs_w), w->O, B, w->O, D), st));
-    VITA_TRY(vita_colsum_f32(s.dz0, D, B, D, s.cs_part, mut(g.obs_b), 0, st));
-    if (d_obs_features) VITA_TRY(gemm_f32(dgrad(s.dz0, D, w->obs_w, w->O, d_obs_features, ld_dobs, B, w->O, D), st));
     VITA_TRY(record(2));
     return VITA_OK;
 }

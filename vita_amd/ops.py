@@ -831,7 +831,7 @@ def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool
                 enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, enc_contrastive_weight: float = 0.0,
                 flow_contrastive_weight: float = 0.0, temperature: float = 0.07, freeze_encoder: bool = False,
                 freeze_decoder: bool = False, kl_weight: float = 0.0, gemm_bf16: int = 0, fm_kind: int = 0,
-                fm_sigma: float = 0.0) -> "L.LossConfig":
+                fm_sigma: float = 0.0, side_streams: bool = False) -> "L.LossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")   # vita_policy.py:71
     c = L.LossConfig()
@@ -841,6 +841,7 @@ def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool
     c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
     c.kl_weight, c.gemm_bf16 = float(kl_weight), int(gemm_bf16)
     c.fm_kind, c.fm_sigma = int(fm_kind), float(fm_sigma)
+    c.side_streams = int(side_streams)
     return c
 
 
