@@ -445,7 +445,10 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
 // workgroups (<= 512 k each, at most 8 splits) and finished by the deterministic second pass.
 static int run_small(const vita_linear_args& a, hipStream_t stream) {
     SplitK sk;
-    if (a.K > 1024) {
+#ifndef VITA_SMALL_NOSPLIT_K
+#define VITA_SMALL_NOSPLIT_K 1024   // 2048 (no grid split for fc2-sized reductions) measured slower: B=128 train step 3.34 -> 3.89 ms
+#endif
+    if (a.K > VITA_SMALL_NOSPLIT_K) {
         int S = (a.K + 511) / 512;
         if (S > 8) S = 8;
         const int64_t ldp = ((int64_t)a.N + 3) & ~int64_t(3);

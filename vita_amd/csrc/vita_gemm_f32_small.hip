@@ -156,7 +156,7 @@ bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws) {
     // one 32 x 32 tile per workgroup re-reads operands (M/32 + N/32) times: keep the L2 traffic of a launch bounded
     const double traffic = ((double)((a.M + 31) / 32) * a.N + (double)((a.N + 31) / 32) * a.M) * a.K * 4.0;
     if (traffic > 96e6) return false;
-    if (a.K > 1024 && !have_splitk_ws) return false;
+    if (a.K > 2048 && !have_splitk_ws) return false;
     return true;
 }
 
