@@ -213,6 +213,10 @@ int cnn_bwd(const vita_encoder_weights& w, const vita_encoder_weights& g, const 
 // ------------------------------------------------------------------------------------------------
 // SimpleFlowNet with saved activations
 // ------------------------------------------------------------------------------------------------
+// Up to this many rows per batch Euler step 0 is evaluated together with the flow-matching rows (launch-bound regime); above,
+// the doubled per-row time path would cost more than the saved launches (B = 4096: 23.0 -> 23.8 ms per step).
+constexpr int kRideAlongMaxRows = 1024;
+
 struct FlowTrainWs {
     // time path over T = B + K rows (flow-matching rows first, then one row per Euler step)
     float *ts, *sin, *hidpre, *hid, *tepre, *silu, *mod, *dmod, *dsilu, *dte, *dhid;
@@ -224,7 +228,7 @@ FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B,
     FlowTrainWs f{};
     // time-path rows: the B per-row timesteps of the flow-matching evaluation, B more for Euler step 0 (t = 0; it is evaluated
     // together with the flow-matching rows, see vita_compute_loss_f32), one per later step
-    const size_t T = K > 0 ? 2 * B + K - 1 : B, E = 1 + K, H = w.H, FF = w.FF, D = w.D, L = w.L, TE = w.TE;
+    const size_t T = K > 0 ? (B <= (size_t)kRideAlongMaxRows ? 2 * B + K - 1 : B + K) : B, E = 1 + K, H = w.H, FF = w.FF, D = w.D, L = w.L, TE = w.TE;
     f.ts = c.take(T);
     f.sin = c.take(T * TE);
     f.hidpre = c.take(T * 4 * TE);
@@ -646,7 +650,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     const bool fe = cfg->freeze_encoder != 0, fd = cfg->freeze_decoder != 0;
     const bool do_sample = cfg->decode_flow_latents != 0 && !fe && !fd;                                                // :153
     const int K = do_sample ? cfg->num_steps : 0;
-    const int T = K > 0 ? 2 * B + K - 1 : B;   // time-path rows: [flow-matching t (B) | step 0: zeros (B) | steps 1..K-1]
+    const bool ride = do_sample && B <= kRideAlongMaxRows;   // Euler step 0 rides along with the flow-matching rows
+    // time-path rows: [flow-matching t (B) | step 0: zeros (B) | steps 1..K-1] when riding along, else [t (B) | steps 0..K-1]
+    const int T = K > 0 ? (ride ? 2 * B + K - 1 : B + K) : B;
+    const int step_row0 = ride ? 2 * B - 1 : B;                // time-path row of Euler step k: step_row0 + k
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
     const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd;                                                           // :183
@@ -683,11 +690,11 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     // time path for the B per-row timesteps of the flow-matching draw and the K Euler steps
     VITA_CHECK_HIP(hipMemcpyAsync(s.flow.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, st));
     if (K > 0) {
-        if (B > 1) VITA_CHECK_HIP(hipMemsetAsync(s.flow.ts + B, 0, (size_t)(B - 1) * 4, st));
-        VITA_TRY(launch_step_times(s.flow.ts + 2 * B - 1, K, st));   // ts[2B-1+k] = k/K; k = 0 closes the zero block
+        if (ride && B > 1) VITA_CHECK_HIP(hipMemsetAsync(s.flow.ts + B, 0, (size_t)(B - 1) * 4, st));
+        VITA_TRY(launch_step_times(s.flow.ts + step_row0, K, st));   // ts[step_row0 + k] = k/K (k = 0 closes the zero block)
     }
     VITA_TRY(time_path_fwd(fc, T));
-    auto step_mod = [&](int k) { return s.flow.mod + (size_t)(2 * B - 1 + k) * ldm; };   // k >= 1: one broadcast row
+    auto step_mod = [&](int k) { return s.flow.mod + (size_t)(step_row0 + k) * ldm; };   // one broadcast row per step
     // flow-matching loss, flow_matchers.py:30-36
     const bool plain_cfm = cfg->fm_kind == VITA_FM_CONDITIONAL && cfg->fm_sigma == 0.f;
     if (plain_cfm) VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
@@ -696,8 +703,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     // they run as ONE 2B-row pass with per-row modulation (one evaluation's worth of launches less per step, forward and
     // backward; at the default B = 128 the step is launch-bound).  Only out_proj differs (v vs x + dt*v) and stays per evaluation.
     const float dt = K > 0 ? (float)(1.0 / (double)K) : 0.f;
-    if (do_sample) {
-        VITA_CHECK_HIP(hipMemcpyAsync(fc.X(1), s.z0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+    if (do_sample) VITA_CHECK_HIP(hipMemcpyAsync(fc.X(1), s.z0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+    if (ride) {
         VITA_TRY(flow_trunk_fwd(fc, 0, 2 * B, s.flow.mod, ldm));
         VITA_TRY(flow_out_fwd(fc, 0, s.vt, D, nullptr, 0, 0.f));
         VITA_TRY(flow_out_fwd(fc, 1, K == 1 ? pred : fc.X(2), D, fc.X(1), D, dt));
@@ -708,7 +715,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     if (nce_enc) VITA_TRY(nce_forward(s.z0, D, z1, D, B, D, tau, losses + VITA_LOSS_ENC_CONTRASTIVE, s.nce_enc, st));              // :134-139
     // Euler sampler with grad, vita_policy.py:153-160 / flow_matchers.py:55-79
     if (do_sample) {
-        for (int k = 1; k < K; ++k) {
+        for (int k = ride ? 1 : 0; k < K; ++k) {
             const int e = k + 1;
             float* dst = (k == K - 1) ? pred : fc.X(e + 1);
             VITA_TRY(flow_eval_fwd(fc, e, step_mod(k), 0, dst, D, fc.X(e), D, dt));
@@ -788,18 +795,22 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     // Euler steps, last to first: dx_k = dx_{k+1} + J_k^T (dt * dx_{k+1}); step 0 shares its pass with the flow-matching rows
     if (do_sample) {
         const float* dxn = dpred;
-        for (int k = K - 1; k >= 1; --k) {
+        for (int k = K - 1; k >= (ride ? 1 : 0); --k) {
             const int e = k + 1;
             VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, dt, fc.DV(e), nullptr, 0, B, D, st));
-            float* dst = (k & 1) ? s.dxa : s.dxb;
+            float* dst = (k == 0) ? s.dz0 : ((k & 1) ? s.dxa : s.dxb);
             VITA_TRY(flow_eval_bwd(fc, e, step_mod(k), 0, s.flow.DM, dst, D, dxn, D));
-            if (L > 0) VITA_TRY(vita_colsum_f32(s.flow.DM, ldm, B, L * 3 * H, s.cs_part, s.flow.dmod + (size_t)(2 * B - 1 + k) * ldm, 0, st));
+            if (L > 0) VITA_TRY(vita_colsum_f32(s.flow.DM, ldm, B, L * 3 * H, s.cs_part, s.flow.dmod + (size_t)(step_row0 + k) * ldm, 0, st));
             dxn = dst;
         }
-        VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, dt, fc.DV(1), nullptr, 0, B, D, st));
-        VITA_TRY(flow_chain_bwd(fc, 0, 2 * B, s.flow.mod, ldm, s.flow.dmod));   // per-row modulation gradients: table rows 0..2B-1
-        VITA_TRY(flow_in_bwd(fc, 0, s.dxt, D, nullptr, 0));
-        VITA_TRY(flow_in_bwd(fc, 1, s.dz0, D, dxn, D));
+        if (ride) {
+            VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, dt, fc.DV(1), nullptr, 0, B, D, st));
+            VITA_TRY(flow_chain_bwd(fc, 0, 2 * B, s.flow.mod, ldm, s.flow.dmod));   // per-row modulation gradients: table rows 0..2B-1
+            VITA_TRY(flow_in_bwd(fc, 0, s.dxt, D, nullptr, 0));
+            VITA_TRY(flow_in_bwd(fc, 1, s.dz0, D, dxn, D));
+        } else {
+            VITA_TRY(flow_eval_bwd(fc, 0, s.flow.mod, ldm, s.flow.dmod, s.dxt, D, nullptr, 0));
+        }
     } else {
         VITA_TRY(flow_eval_bwd(fc, 0, s.flow.mod, ldm, s.flow.dmod, s.dxt, D, nullptr, 0));
         VITA_CHECK_HIP(hipMemsetAsync(s.dz0, 0, (size_t)B * D * 4, st));
