@@ -237,6 +237,46 @@ def main():
                              "frac_of_f32_mfma_peak": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
     dom = FC1
 
+    # ---- HBM-bound kernels (loss / elementwise / optimizer): achieved GB/s of algorithmic bytes against the 8 TB/s HBM3E peak
+    hbm = {}
+    if rank == 0:
+        def time_op(fn, reps=20):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                fn()
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e-3 / reps
+        R, Dl, Hh = 7 * B, fw.D, fw.H          # rows of one stacked training pass (1 + K evaluations)
+        xa, xb = torch.randn(R, Dl, device=dev), torch.randn(R, Dl, device=dev)
+        tt = torch.rand(R, device=dev)
+        one = torch.ones((), device=dev)
+        hh, dyh = torch.randn(R, Hh, device=dev), torch.randn(R, Hh, device=dev)
+        mul, add = torch.randn(Hh, device=dev) * 0.1, torch.randn(Hh, device=dev) * 0.1
+        nparam = 19_925_328
+        pp, gg, mm, vv, ee = (torch.randn(nparam, device=dev) * 0.01 for _ in range(5))
+        vv.abs_()
+        gsq = ops.sumsq(gg)
+        cases = {
+            f"mse_loss_fwd {R}x{Dl}": (lambda: ops.mse_loss_fwd(xa, xb), 8 * R * Dl),
+            f"mse_loss_bwd {R}x{Dl} (one gradient)": (lambda: ops.mse_loss_bwd(xa, xb, one, need_b=False), 12 * R * Dl),
+            f"cfm_interpolate {R}x{Dl}": (lambda: ops.cfm_interpolate(xa, xb, tt), 16 * R * Dl),
+            f"layernorm_modulate fwd {R}x{Hh}": (lambda: ops.layernorm_modulate(hh, mul, add, 1e-6), 8 * R * Hh),
+            f"layernorm_modulate bwd {R}x{Hh} (dx + dmul/dadd rows)": (lambda: ops.layernorm_modulate_bwd(hh, dyh, mul, 1e-6, _lib.PRO_LN_MOD), 24 * R * Hh),
+            f"colsum {R}x{Hh}": (lambda: ops.colsum(hh), 4 * R * Hh),
+            f"sumsq {nparam}": (lambda: ops.sumsq(gg), 4 * nparam),
+            f"adamw_ema_step {nparam} (clip + AdamW + EMA, one pass)": (
+                lambda: ops.adamw_ema_step(pp, gg, mm, vv, ee, step=10, lr=1e-4, gnorm_sq=gsq, max_norm=1.0, ema_decay=0.5), 36 * nparam),
+        }
+        for name, (fn, nbytes) in cases.items():
+            dt_ = time_op(fn)
+            hbm[name] = {"avg_us": round(dt_ * 1e6, 2), "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / dt_ / 1e9, 1),
+                         "frac_of_hbm_peak": round(nbytes / dt_ / 8e12, 4)}
+        del xa, xb, hh, dyh, pp, gg, mm, vv, ee
+
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
@@ -292,6 +332,8 @@ def main():
                          "timing": "HIP events around 20 back-to-back launches on the launch stream: includes the gap between "
                                    "dependent kernels; rocprofv3's per-kernel duration (profiles/) excludes it, see DESIGN.md section 4"},
             "kernels": kernels,
+            "hbm_bound_kernels": {"peak_GB_per_s": 8000, "note": "wrapper calls incl. their output allocation; algorithmic bytes = reads + writes "
+                                  "of the operands once", "kernels": hbm},
             "train": train,
             "train_large_batch": train_large,
             "train_large_batch_bf16": train_large_bf16,
