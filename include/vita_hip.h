@@ -456,6 +456,33 @@ size_t vita_meanflow_sample_workspace_bytes(const vita_meanflow_weights* w, int3
 int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
                              int32_t num_steps, void* workspace, size_t workspace_bytes, vita_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * MeanFlow TRAINING step (flow_matcher.name = "mean", flow_net.name = "simple_mean_flow_net"): VitaPolicy.compute_loss
+ * (vita_policy.py:112-189) with MeanFlowMatcher.compute_loss (flow/mean_flow_matcher.py:109-199, use_imf = False,
+ * dispersive_loss_weight = 0) and the MeanFlow sampler with grad (:201-233), forward + backward in one call.
+ *   t, r (B): the (t, r) draw of sample_t_r (:87-107), made by the caller.
+ *   losses: device float[VITA_LOSS_COUNT]; VITA_LOSS_FLOW holds meanflow_loss, the other entries as in vita_compute_loss_f32.
+ *   grads: NULL = forward only; else every gradient buffer is overwritten (the v head's with zeros: it takes no part).
+ * Not built here: improved MeanFlow (use_imf), the dispersive term, the variational encoder, freeze flags, contrastive terms. */
+typedef struct vita_meanflow_policy_weights {
+    int32_t O;
+    const float *obs_w, *obs_b;
+    vita_meanflow_weights flow;
+    vita_encoder_weights enc;
+    vita_decoder_weights dec;
+} vita_meanflow_policy_weights;
+typedef struct vita_meanflow_loss_config {
+    int32_t num_steps, recon_l1, decode_flow_latents;
+    float consistency_weight, enc_recon_weight, flow_recon_weight;
+    float adaptive_loss_gamma;   /* MeanFlowMatcher(adaptive_loss_gamma=0.5) */
+    float adaptive_loss_c;       /* adaptive_l2_loss(c=1e-3), mean_flow_matcher.py:10 */
+} vita_meanflow_loss_config;
+size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_weights* w, const vita_meanflow_loss_config* cfg, int32_t B);
+int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
+                                   const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
+                                   const float* t, const float* r, int32_t B, float* losses, void* workspace, size_t workspace_bytes,
+                                   vita_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -359,6 +359,73 @@ def mean_flow_sample(sd: SD, start: Tensor, num_steps: int = 1, prefix: str = "f
     return x
 
 
+def mean_flow_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, r: Tensor, adaptive_loss_gamma: float = 0.5,
+                   c: float = 1e-3, prefix: str = "flow_net.") -> Tensor:
+    """MeanFlowMatcher.compute_loss, mean_flow_matcher.py:109-183 with use_imf = False and dispersive_loss_weight = 0;
+    (t, r) — the reference's sample_t_r draw (:87-107) — are explicit inputs.  adaptive_l2_loss: :10-18."""
+    x1, x0 = target, start
+    t_ = t.view(-1, *([1] * (x0.dim() - 1)))
+    h_ = (t - r).view(-1, *([1] * (x0.dim() - 1)))
+    z_t = (1 - t_) * x1 + t_ * x0                                                 # :129
+    v = x0 - x1                                                                   # :132
+
+    def pred_u(z_in, t_in, r_in):
+        return mean_flow_net_forward(sd, z_in, t_in, t_in - r_in, prefix)[0]
+
+    u, dudt = torch.autograd.functional.jvp(pred_u, (z_t, t, r), (v, torch.ones_like(t), torch.zeros_like(r)), create_graph=True)  # :171-176
+    u_tgt = v - h_ * dudt                                                         # :178
+    error = u - u_tgt.detach()
+    delta_sq = torch.mean(error ** 2, dim=tuple(range(1, error.ndim)))
+    w = 1.0 / (delta_sq + c).pow(1.0 - adaptive_loss_gamma)
+    return (w.detach() * delta_sq).mean()
+
+
+def mean_flow_sample_grad(sd: SD, start: Tensor, num_steps: int = 1, prefix: str = "flow_net.") -> Tensor:
+    """MeanFlowMatcher.sample (:201-233) keeping the graph (vita_policy.py:154-160 calls it with grad)."""
+    x = start
+    B = x.shape[0]
+    for step in range(num_steps):
+        t_scalar = 1.0 - step / num_steps
+        r_scalar = 1.0 - (step + 1) / num_steps
+        t = torch.full((B,), t_scalar, dtype=x.dtype)
+        h = torch.full((B,), t_scalar - r_scalar, dtype=x.dtype)
+        u = mean_flow_net_forward(sd, x, t, h, prefix)[0]
+        x = x - h.view(-1, *([1] * (x.dim() - 1))) * u
+    return x
+
+
+def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, r: Tensor, num_steps: int = 1,
+                          consistency_weight: float = 1.0, enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5,
+                          recon_loss_type: str = "l1", decode_flow_latents: bool = True, adaptive_loss_gamma: float = 0.5):
+    """VitaPolicy.compute_loss (vita_policy.py:112-189) with flow_matcher.name = 'mean' over SimpleMeanFlowNet: defaults
+    otherwise (plain autoencoder, nothing frozen, no contrastive terms).  Returns (loss, metrics of 0-dim tensors)."""
+    recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
+    T, A = gt_actions.shape[1], gt_actions.shape[2]
+    m = {}
+    obs_latents = obs_encode(sd, obs_features)
+    action_latents = action_encode(sd, gt_actions)
+    flow_loss = mean_flow_loss(sd, obs_latents, action_latents, t, r, adaptive_loss_gamma)        # :126-130
+    loss = flow_loss
+    m["meanflow_loss"] = flow_loss
+    m["flow_loss"] = flow_loss
+    if decode_flow_latents:                                                                        # :153-178
+        pred = mean_flow_sample_grad(sd, obs_latents, num_steps)
+        if consistency_weight > 0:
+            cterm = F.mse_loss(pred, action_latents)
+            loss = loss + consistency_weight * cterm
+            m["consistency_loss"] = cterm
+        if flow_recon_weight > 0:
+            rterm = recon(simple_action_decode(sd, pred, T, A), gt_actions)
+            m["flow_action_recon_loss"] = rterm
+            loss = loss + flow_recon_weight * rterm
+    if enc_recon_weight > 0:                                                                       # :183-187
+        rterm = recon(simple_action_decode(sd, action_latents, T, A), gt_actions)
+        m["enc_action_recon_loss"] = rterm
+        loss = loss + enc_recon_weight * rterm
+    m["loss"] = loss
+    return loss, m
+
+
 def make_meanflow_state_dict(latent_dim: int = 512, hidden_dim: int = 512, num_layers: int = 4, mlp_ratio: float = 4.0,
                              seed: int = 0, dtype=torch.float32, prefix: str = "flow_net.") -> SD:
     """Seeded weights with SimpleMeanFlowNet's keys; the output layers are NOT zero (the reference zero-initialises

@@ -1,0 +1,110 @@
+"""GPU parity of the MeanFlow training step (vita_compute_loss_meanflow_f32: MeanFlowMatcher.compute_loss with its JVP
+target, the MeanFlow sampler with grad, encoder / decoder terms; forward + backward) against tests/golden/
+meanflow_train.safetensors — losses and every gradient from the reference's own MeanFlowMatcher / SimpleMeanFlowNet /
+CNNActionEncoder / SimpleActionDecoder and torch autograd (tools/gen_golden_meanflow.py) — and against the oracle in fp64.
+Tolerances: losses 1e-5 relative, gradients 2e-5 normalised max error."""
+import os
+
+import pytest
+import torch
+from safetensors import safe_open
+
+from oracle import vita_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test running without a GPU")
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from vita_amd import _lib, ops as _ops
+    _lib.load()
+    return _ops
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    out = {}
+    with safe_open(os.path.join(golden_dir, "meanflow_train.safetensors"), framework="pt") as f:
+        for k in f.keys():
+            out[k] = f.get_tensor(k)
+    return out
+
+
+def nerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
+
+
+def run(ops, dev, sd, obs, actions, t, r, cfg):
+    sdd = {k: v.to(dev).contiguous() for k, v in sd.items()}
+    gsd = {k: torch.full_like(v, float("nan")) for k, v in sdd.items()}
+    pw = ops.MeanFlowPolicyHandle(sdd, dev, pred_horizon=actions.shape[1], strict=True)
+    gw = ops.MeanFlowPolicyHandle(gsd, dev, pred_horizon=actions.shape[1], strict=True)
+    losses = ops.compute_loss_meanflow(pw, cfg, obs.to(dev), actions.to(dev), t.to(dev), r.to(dev), grads=gw)
+    torch.cuda.synchronize()
+    return losses.cpu(), {k: v.cpu() for k, v in gsd.items()}
+
+
+KEYS = {"loss": 0, "meanflow_loss": 1, "consistency_loss": 2, "flow_action_recon_loss": 3, "enc_action_recon_loss": 4}
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K):
+    sd = {k[len("mf/sd/"):]: v for k, v in gold.items() if k.startswith("mf/sd/")}
+    obs, actions, t, r = (gold["mf/" + k] for k in ("obs_features", "actions", "t", "r"))
+    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K))
+    for k, i in KEYS.items():
+        ref = gold[f"mf/K{K}/loss/{k}"].item()
+        assert abs(losses[i].item() - ref) <= 1e-5 * abs(ref), f"K={K} {k}: {losses[i].item()} vs {ref}"
+    for k in sd:
+        ref = gold[f"mf/K{K}/grad/{k}"]
+        assert torch.isfinite(grads[k]).all(), k
+        if ref.abs().max().item() == 0:
+            assert grads[k].abs().max().item() == 0, f"grad {k} should be zero"
+        else:
+            assert nerr(grads[k], ref) <= 2e-5, f"K={K} grad {k}: {nerr(grads[k], ref):g}"
+
+
+@pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma"])
+def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
+    g = torch.Generator().manual_seed(31)
+    kw, ck = {}, {}
+    if variant == "default_dims_b64":
+        A, T, B, D, H, Lh, O_, enc, aeh, ael = 21, 16, 64, 512, 512, 4, 533, "cnn", 512, 4
+    else:
+        A, T, B, D, H, Lh, O_, enc, aeh, ael = 7, 16, 19, 64, 64, 3, 40, ("simple" if variant == "l2_simple_encoder" else "cnn"), 48, (2 if variant == "l2_simple_encoder" else 4)
+    base = O.make_state_dict(O_, A, latent_dim=D, hidden_dim=64, num_layers=1, pred_horizon=T, ae_hidden=aeh, ae_layers=ael, time_embed_dim=16,
+                             seed=41, encoder_type=enc)
+    sd = {k: v for k, v in base.items() if not k.startswith("flow_net.")}
+    sd.update(O.make_meanflow_state_dict(D, H, Lh, 4.0, seed=42))
+    K = 2
+    if variant == "l2_simple_encoder":
+        kw.update(recon_loss_type="l2"); ck.update(recon="l2")
+    if variant == "no_decode":
+        kw.update(decode_flow_latents=False); ck.update(decode_flow_latents=False)
+    if variant == "gamma":
+        kw.update(adaptive_loss_gamma=0.2); ck.update(adaptive_loss_gamma=0.2)
+        K = 1
+    obs, actions = torch.randn(B, O_, generator=g), torch.randn(B, T, A, generator=g)
+    smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
+    t, r = smp.max(1)[0], smp.min(1)[0]
+    r[: B // 2] = t[: B // 2]
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    loss, m = O.compute_loss_meanflow(sd64, obs.double(), actions.double(), t.double(), r.double(), K, **kw)
+    keys = list(sd64)
+    gs = torch.autograd.grad(loss, [sd64[k] for k in keys], allow_unused=True)
+    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, **ck))
+    assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item()), (losses[0].item(), loss.item())
+    assert abs(losses[1].item() - m["meanflow_loss"].item()) <= 1e-5 * abs(m["meanflow_loss"].item())
+    for k, gr in zip(keys, gs):
+        if gr is None or gr.abs().max().item() == 0:
+            assert grads[k].abs().max().item() == 0, f"{variant}: grad {k} should be zero"
+        else:
+            assert nerr(grads[k], gr) <= 2e-5, f"{variant}: grad {k} {nerr(grads[k], gr):g}"

@@ -107,6 +107,24 @@ class LossConfig(C.Structure):
     ]
 
 
+class MeanFlowPolicyWeights(C.Structure):
+    _fields_ = [
+        ("O", C.c_int32),
+        ("obs_w", c_fp), ("obs_b", c_fp),
+        ("flow", MeanFlowWeights),
+        ("enc", EncoderWeights),
+        ("dec", DecoderWeights),
+    ]
+
+
+class MeanFlowLossConfig(C.Structure):
+    _fields_ = [
+        ("num_steps", C.c_int32), ("recon_l1", C.c_int32), ("decode_flow_latents", C.c_int32),
+        ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
+        ("adaptive_loss_gamma", C.c_float), ("adaptive_loss_c", C.c_float),
+    ]
+
+
 class Bf16Weights(C.Structure):
     _fields_ = [
         ("obs_w", c_fp), ("in_w", c_fp), ("out_w", c_fp),
@@ -194,6 +212,10 @@ SIGNATURES = {
     "vita_meanflow_sample_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowWeights), C.c_int32, C.c_int32]),
     "vita_meanflow_sample_f32": (C.c_int, [C.POINTER(MeanFlowWeights), c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp,
                                            C.c_size_t, c_fp]),
+    "vita_compute_loss_meanflow_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowLossConfig), C.c_int32]),
+    "vita_compute_loss_meanflow_f32": (C.c_int, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowPolicyWeights),
+                                                 C.POINTER(MeanFlowLossConfig), c_fp, C.c_int64, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp,
+                                                 C.c_size_t, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

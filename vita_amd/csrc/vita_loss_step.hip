@@ -895,3 +895,435 @@ int vita_action_encoder_forward_f32(const vita_encoder_weights* w, const float* 
 }
 
 }  // extern "C"
+
+// =================================================================================================
+// MeanFlow training step: VitaPolicy.compute_loss with flow_matcher.name = "mean" over SimpleMeanFlowNet
+// (mean_flow_matcher.py:109-199, use_imf = False; simple_mean_flow_net.py:63-81; vita_policy.py:112-189), forward + backward.
+//
+//   t, r given (sample_t_r is the host's draw, :87-107); h = t - r; z_t = (1-t)*x1 + t*x0; v = x0 - x1           :123-132
+//   (u, dudt) = jvp(u(z, t, r), (z_t, t, r), (v, 1, 0))                                                           :171-176
+//   err = u - stopgrad(v - h*dudt); loss_mf = mean_b( stopgrad(1 / (mean_d err^2 + c)^(1-gamma)) * mean_d err^2 ) :178-180, 10-18
+//   pred = MeanFlow sampler from x0 with grad (x <- x - h*u(x, t_k, h_k), :201-233); consistency / reconstruction terms as in
+//   the default policy.
+// The target is detached, so only the PRIMAL evaluation is differentiated: the tangent pass is forward-only and rides the
+// same weights — every Linear once more on the tangent rows without its bias, every SiLU as silu'(primal pre-activation) *
+// tangent (vita_act_bwd_f32) — and the backward is the ordinary one of a residual MLP.  As in the default step the 1 + K
+// evaluations are stacked so that each weight gets one wgrad GEMM; the gradient of the time conditioning telescopes:
+// sum_l d x_cond_l = d x_0 - d x_L.
+// =================================================================================================
+namespace vita {
+namespace {
+
+constexpr int MFT = 256;
+// tv/hv rows: [0,B) = (t, t - r); B + k = (1 - k/K, (1 - k/K) - (1 - (k+1)/K)) in double as the reference's python floats; ones[b] = 1
+__global__ __launch_bounds__(MFT) void mf_prep_kernel(const float* __restrict__ t, const float* __restrict__ r, float* __restrict__ tv,
+                                                     float* __restrict__ hv, float* __restrict__ ones, int B, int K) {
+    const int i = blockIdx.x * MFT + threadIdx.x;
+    if (i < B) { tv[i] = t[i]; hv[i] = t[i] - r[i]; ones[i] = 1.0f; }
+    else if (i < B + K) {
+        const int k = i - B;
+        const double ts = 1.0 - (double)k / (double)K, rs = 1.0 - (double)(k + 1) / (double)K;
+        tv[i] = (float)ts;
+        hv[i] = (float)(ts - rs);
+    }
+}
+// one wave per row: err = u - (v - h*dudt); delta = mean_d err^2; w = 1 / (delta + c)^p; rows[b] = w * delta, wrow[b] = w
+__global__ __launch_bounds__(MFT) void mf_loss_rows_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ dudt,
+                                                          const float* __restrict__ hv, int B, int D, float p, float c, float* __restrict__ rows,
+                                                          float* __restrict__ wrow) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float h = hv[row];
+    float s = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const int64_t i = (int64_t)row * D + k;
+        const float e = u[i] - (v[i] - h * dudt[i]);
+        s += e * e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float delta = s / (float)D;
+        const float w = 1.0f / powf(delta + c, p);
+        rows[row] = w * delta;
+        wrow[row] = w;
+    }
+}
+__global__ __launch_bounds__(MFT) void mf_mean_kernel(const float* __restrict__ a, int n, float* __restrict__ out) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += MFT) s += (double)a[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[MFT / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(((ws[0] + ws[1]) + (ws[2] + ws[3])) / (double)n);
+}
+// du = (1/B) * w_b * (2/D) * err      (w and the target detached)
+__global__ __launch_bounds__(MFT) void mf_loss_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ dudt,
+                                                         const float* __restrict__ hv, const float* __restrict__ wrow, int B, int D,
+                                                         float* __restrict__ du) {
+    const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * MFT;
+    for (int64_t i = (int64_t)blockIdx.x * MFT + threadIdx.x; i < n; i += stride) {
+        const int row = (int)(i / D);
+        const float e = u[i] - (v[i] - hv[row] * dudt[i]);
+        du[i] = (wrow[row] / (float)B) * ((2.0f / (float)D) * e);
+    }
+}
+__global__ __launch_bounds__(MFT) void mf_sub_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * MFT;
+    for (int64_t i = (int64_t)blockIdx.x * MFT + threadIdx.x; i < n; i += stride) out[i] = a[i] - b[i];
+}
+inline unsigned mfgrid(int64_t n) {
+    const int64_t b = (n + MFT - 1) / MFT;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+struct MfTrainWs {
+    float *sk, *consts, *loss_part, *cs_part;
+    float *tv, *hv, *ones, *At, *St, *Ah, *Sh, *tc;              // conditioning rows T = B + K
+    float *dAt, *dSt, *dtc_tan;                                    // tangent of the conditioning (B rows)
+    float *X0, *Xs, *Xc, *U1, *S;                                  // stacked evaluations
+    float *xd0, *xd1, *xcd, *u1d, *sd, *dudt;                      // tangent pass (B rows)
+    float *z0, *ZZ, *v, *u0, *rows, *wrow;
+    float *DU, *DX, *dz0, *dZZ, *dxa, *dxb, *dzt, *dtc, *dtmp, *dA1;
+    StackWs dec, senc;
+    CnnWs cnn;
+    size_t bytes;
+};
+int max_colsum_n_mf(const vita_meanflow_policy_weights& w) {
+    int n = w.flow.FF;
+    auto up = [&](int v) { if (v > n) n = v; };
+    up(w.flow.H); up(w.flow.D); up(w.dec.HD); up(w.dec.OUT); up(w.dec.D); up(w.enc.C * 4); up(w.enc.D);
+    return n;
+}
+MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const vita_meanflow_loss_config& cfg, size_t B) {
+    Carver c(ws);
+    MfTrainWs s{};
+    const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0, T = B + K, E = 1 + K;
+    const size_t D = w.flow.D, H = w.flow.H, FF = w.flow.FF, L = w.flow.L;
+    s.sk = c.take(kSplitkBytes / sizeof(float));
+    s.consts = c.take(16);
+    s.loss_part = c.take((size_t)vita_loss_partials_count());
+    s.cs_part = c.take((size_t)vita_colsum_partials_count(max_colsum_n_mf(w)));
+    s.tv = c.take(T); s.hv = c.take(T); s.ones = c.take(B);
+    s.At = c.take(T * H); s.St = c.take(T * H); s.Ah = c.take(T * H); s.Sh = c.take(T * H); s.tc = c.take(T * H);
+    s.dAt = c.take(B * H); s.dSt = c.take(B * H); s.dtc_tan = c.take(B * H);
+    s.X0 = c.take(E * B * D);
+    s.Xs = c.take((L + 1) * E * B * H);
+    s.Xc = c.take((L ? L : 1) * E * B * H);
+    s.U1 = c.take((L ? L : 1) * E * B * FF);
+    s.S = c.take((L ? L : 1) * E * B * FF);
+    s.xd0 = c.take(B * H); s.xd1 = c.take(B * H); s.xcd = c.take(B * H); s.u1d = c.take(B * FF); s.sd = c.take(B * FF); s.dudt = c.take(B * D);
+    s.z0 = c.take(B * D); s.ZZ = c.take(2 * B * D); s.v = c.take(B * D); s.u0 = c.take(B * D); s.rows = c.take(B); s.wrow = c.take(B);
+    s.DU = c.take(E * B * D);
+    s.DX = c.take((L + 1) * E * B * H);
+    s.dz0 = c.take(B * D); s.dZZ = c.take(2 * B * D); s.dxa = c.take(B * D); s.dxb = c.take(B * D); s.dzt = c.take(B * D);
+    s.dtc = c.take(T * H); s.dtmp = c.take(B * H); s.dA1 = c.take(T * H);
+    s.dec = carve_stack(c, stack_of(w.dec), 2 * B, true);
+    if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, true);
+    else s.cnn = carve_cnn(c, w.enc, B, true);
+    s.bytes = c.off;
+    return s;
+}
+
+struct MfCtx {
+    const vita_meanflow_weights* w;
+    const MfTrainWs* s;
+    int B, E;
+    hipStream_t st;
+    size_t bh() const { return (size_t)B * w->H; }
+    size_t bf() const { return (size_t)B * w->FF; }
+    float* X0(int e) const { return s->X0 + (size_t)e * B * w->D; }
+    float* Xs(int l, int e) const { return s->Xs + ((size_t)l * E + e) * bh(); }
+    float* Xc(int l, int e) const { return s->Xc + ((size_t)l * E + e) * bh(); }
+    float* U1(int l, int e) const { return s->U1 + ((size_t)l * E + e) * bf(); }
+    float* S(int l, int e) const { return s->S + ((size_t)l * E + e) * bf(); }
+    float* DU(int e) const { return s->DU + (size_t)e * B * w->D; }
+    float* DX(int l, int e) const { return s->DX + ((size_t)l * E + e) * bh(); }
+};
+
+// trunk of evaluation e with saved activations; tc: conditioning rows (ld_tc = H per row, 0 = one shared row)
+int mf_trunk_fwd(const MfCtx& c, int e, const float* tc, int64_t ld_tc) {
+    const vita_meanflow_weights* w = c.w;
+    const int D = w->D, H = w->H, FF = w->FF, B = c.B;
+    VITA_TRY(gemm_f32(lin(c.X0(e), D, w->in_w, D, w->in_b, c.Xs(0, e), H, B, H, D, VITA_ACT_NONE), c.st));
+    for (int l = 0; l < w->L; ++l) {
+        VITA_TRY(launch_add_rows(c.Xs(l, e), H, tc, ld_tc, c.Xc(l, e), H, B, H, c.st));
+        vita_linear_args a = lin(c.Xc(l, e), H, w->fc1_w[l], H, w->fc1_b[l], c.S(l, e), FF, B, FF, H, VITA_ACT_SILU);
+        a.preact = c.U1(l, e); a.ld_preact = FF;
+        VITA_TRY(gemm_f32(a, c.st));
+        vita_linear_args b = lin(c.S(l, e), FF, w->fc2_w[l], FF, w->fc2_b[l], c.Xs(l + 1, e), H, B, H, FF, VITA_ACT_NONE);
+        b.resid = c.Xs(l, e); b.ld_resid = H;
+        VITA_TRY(gemm_f32(b, c.st));
+    }
+    return VITA_OK;
+}
+// tangent pass of evaluation 0: xdot through the same weights, no biases; returns dudt (B, D)
+int mf_tangent_fwd(const MfCtx& c, const float* dz, const float* dtc) {
+    const vita_meanflow_weights* w = c.w;
+    const MfTrainWs& s = *c.s;
+    const int D = w->D, H = w->H, FF = w->FF, B = c.B;
+    float* xd = s.xd0;
+    float* xn = s.xd1;
+    VITA_TRY(gemm_f32(lin(dz, D, w->in_w, D, nullptr, xd, H, B, H, D, VITA_ACT_NONE), c.st));
+    for (int l = 0; l < w->L; ++l) {
+        VITA_TRY(launch_add_rows(xd, H, dtc, H, s.xcd, H, B, H, c.st));
+        VITA_TRY(gemm_f32(lin(s.xcd, H, w->fc1_w[l], H, nullptr, s.u1d, FF, B, FF, H, VITA_ACT_NONE), c.st));
+        VITA_TRY(vita_act_bwd_f32(c.U1(l, 0), s.u1d, s.sd, (int64_t)B * FF, VITA_ACT_SILU, c.st));      // sdot = silu'(u1) * u1dot
+        vita_linear_args b = lin(s.sd, FF, w->fc2_w[l], FF, nullptr, xn, H, B, H, FF, VITA_ACT_NONE);
+        b.resid = xd; b.ld_resid = H;
+        VITA_TRY(gemm_f32(b, c.st));
+        float* t_ = xd; xd = xn; xn = t_;
+    }
+    return gemm_f32(lin(xd, H, w->u_w, H, nullptr, s.dudt, D, B, D, H, VITA_ACT_NONE), c.st);
+}
+// input-gradient chain of evaluation e from DU(e); leaves DX(l, e) for every l, dU1 in U1(l, e); dx = resid + DX(0,e) . W_in
+int mf_chain_bwd(const MfCtx& c, int e, float* dx, int64_t ld_dx, const float* resid, int64_t ld_resid) {
+    const vita_meanflow_weights* w = c.w;
+    const int D = w->D, H = w->H, FF = w->FF, B = c.B, L = w->L;
+    VITA_TRY(gemm_f32(dgrad(c.DU(e), D, w->u_w, H, c.DX(L, e), H, B, H, D), c.st));
+    for (int l = L - 1; l >= 0; --l) {
+        vita_linear_args a = dgrad(c.DX(l + 1, e), H, w->fc2_w[l], FF, c.U1(l, e), FF, B, FF, H);        // dU1 = (dY . W2) * silu'(U1), in place
+        a.act = VITA_ACT_SILU; a.act_grad_z = c.U1(l, e); a.ld_act_grad_z = FF;
+        VITA_TRY(gemm_f32(a, c.st));
+        vita_linear_args b = dgrad(c.U1(l, e), FF, w->fc1_w[l], H, c.DX(l, e), H, B, H, FF);             // dx_l = dx_{l+1} + dU1 . W1
+        b.resid = c.DX(l + 1, e); b.ld_resid = H;
+        VITA_TRY(gemm_f32(b, c.st));
+    }
+    vita_linear_args a = dgrad(c.DX(0, e), H, w->in_w, D, dx, ld_dx, B, D, H);
+    if (resid) { a.resid = resid; a.ld_resid = ld_resid; }
+    return gemm_f32(a, c.st);
+}
+int check_mfw(const vita_meanflow_weights* w, const char* who) {
+    VITA_REQUIRE(w->D > 0 && w->H > 0 && w->FF > 0 && w->L >= 0 && w->L <= VITA_MAX_LAYERS, "%s: bad mean-flow dims", who);
+    VITA_REQUIRE(w->t1_w && w->t1_b && w->t2_w && w->t2_b && w->h1_w && w->h1_b && w->h2_w && w->h2_b && w->in_w && w->in_b && w->u_w && w->u_b,
+                 "%s: null mean-flow weight pointer", who);
+    for (int l = 0; l < w->L; ++l) VITA_REQUIRE(w->fc1_w[l] && w->fc1_b[l] && w->fc2_w[l] && w->fc2_b[l], "%s: null weight pointer in layer %d", who, l);
+    return VITA_OK;
+}
+
+}  // namespace
+}  // namespace vita
+
+extern "C" {
+
+size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_weights* w, const vita_meanflow_loss_config* cfg, int32_t B) {
+    if (!w || !cfg || B <= 0) return 0;
+    return carve_mf_train(nullptr, *w, *cfg, (size_t)B).bytes;
+}
+
+int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
+                                   const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
+                                   const float* t, const float* r, int32_t B, float* losses, void* workspace, size_t workspace_bytes,
+                                   vita_stream_t stream) {
+    const char* who = "vita_compute_loss_meanflow_f32";
+    VITA_REQUIRE(w && cfg, "%s: null weights / config", who);
+    VITA_REQUIRE(w->O > 0 && w->obs_w && w->obs_b, "%s: bad obs_encoder", who);
+    VITA_TRY(check_mfw(&w->flow, who));
+    VITA_TRY(check_dec_weights(&w->dec, who));
+    VITA_TRY(check_enc_weights(&w->enc, who));
+    VITA_REQUIRE(!w->enc.variational, "%s: the variational encoder is not built for the MeanFlow step", who);
+    VITA_REQUIRE(w->flow.D == w->dec.D && w->flow.D == w->enc.D && w->dec.OUT == w->enc.T * w->enc.A, "%s: latent / action dims differ", who);
+    VITA_REQUIRE(B >= 1 && obs_features && actions && t && r && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/r/losses", who);
+    VITA_REQUIRE(!cfg->decode_flow_latents || cfg->num_steps >= 1, "%s: num_steps must be >= 1", who);
+    VITA_REQUIRE(cfg->consistency_weight >= 0.f && cfg->enc_recon_weight >= 0.f && cfg->flow_recon_weight >= 0.f && cfg->adaptive_loss_c > 0.f,
+                 "%s: bad loss weights", who);
+    if (grads) {
+        VITA_TRY(check_mfw(&grads->flow, "vita_compute_loss_meanflow_f32 (grads)"));
+        VITA_TRY(check_dec_weights(&grads->dec, who));
+        VITA_TRY(check_enc_weights(&grads->enc, who));
+        VITA_REQUIRE(grads->obs_w && grads->obs_b && grads->O == w->O && grads->flow.D == w->flow.D && grads->flow.H == w->flow.H &&
+                         grads->flow.FF == w->flow.FF && grads->flow.L == w->flow.L && grads->dec.HD == w->dec.HD && grads->dec.NL == w->dec.NL &&
+                         grads->dec.OUT == w->dec.OUT && grads->enc.kind == w->enc.kind && grads->enc.C == w->enc.C && grads->enc.NL == w->enc.NL &&
+                         grads->enc.A == w->enc.A && grads->enc.T == w->enc.T,
+                     "%s: the gradient descriptor's dims differ from the weights'", who);
+    }
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_compute_loss_meanflow_workspace_bytes(w, cfg, B), who));
+    hipStream_t st = (hipStream_t)stream;
+    MfTrainWs s = carve_mf_train(workspace, *w, *cfg, (size_t)B);
+    const vita_meanflow_weights* fw = &w->flow;
+    const int D = fw->D, H = fw->H, FF = fw->FF, L = fw->L, OUT = w->dec.OUT;
+    const bool do_sample = cfg->decode_flow_latents != 0;
+    const int K = do_sample ? cfg->num_steps : 0, T = B + K, E = 1 + K;
+    const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
+    const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
+    const bool dec_enc = cfg->enc_recon_weight > 0.f;
+    float* pred = s.ZZ;
+    float* z1 = s.ZZ + (size_t)B * D;
+    MfCtx mc{fw, &s, B, E, st};
+    SplitkScope skscope(s.sk, kSplitkBytes);
+    const float seeds[4] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight};
+    VITA_TRY(launch_set_scalars(s.consts, seeds, 4, st));
+    VITA_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * VITA_LOSS_COUNT, st));
+
+    // ---- forward ------------------------------------------------------------------------------
+    VITA_TRY(gemm_f32(lin(obs_features, ldobs, w->obs_w, w->O, w->obs_b, s.z0, D, B, D, w->O, VITA_ACT_NONE), st));
+    {
+        StepWs es{};
+        es.senc = s.senc; es.cnn = s.cnn;
+        VITA_TRY(encoder_fwd(w->enc, es, actions, z1, D, B, st));
+    }
+    hipLaunchKernelGGL(mf_prep_kernel, dim3((T + MFT - 1) / MFT), dim3(MFT), 0, st, t, r, s.tv, s.hv, s.ones, B, K);
+    VITA_CHECK_HIP(hipGetLastError());
+    // time conditioning for the T rows, keeping the pre-activations              simple_mean_flow_net.py:64-67
+    {
+        vita_linear_args a = lin(s.tv, 1, fw->t1_w, 1, fw->t1_b, s.St, H, T, H, 1, VITA_ACT_SILU);
+        a.preact = s.At; a.ld_preact = H;
+        VITA_TRY(gemm_f32(a, st));
+        VITA_TRY(gemm_f32(lin(s.St, H, fw->t2_w, H, fw->t2_b, s.tc, H, T, H, H, VITA_ACT_NONE), st));
+        vita_linear_args b = lin(s.hv, 1, fw->h1_w, 1, fw->h1_b, s.Sh, H, T, H, 1, VITA_ACT_SILU);
+        b.preact = s.Ah; b.ld_preact = H;
+        VITA_TRY(gemm_f32(b, st));
+        vita_linear_args d = lin(s.Sh, H, fw->h2_w, H, fw->h2_b, s.tc, H, T, H, H, VITA_ACT_NONE);
+        d.resid = s.tc; d.ld_resid = H;
+        VITA_TRY(gemm_f32(d, st));
+    }
+    // its tangent along (tdot, rdot) = (1, 0): tdot = 1 and hdot = 1
+    {
+        VITA_TRY(gemm_f32(lin(s.ones, 1, fw->t1_w, 1, nullptr, s.dAt, H, B, H, 1, VITA_ACT_NONE), st));
+        VITA_TRY(vita_act_bwd_f32(s.At, s.dAt, s.dSt, (int64_t)B * H, VITA_ACT_SILU, st));
+        VITA_TRY(gemm_f32(lin(s.dSt, H, fw->t2_w, H, nullptr, s.dtc_tan, H, B, H, H, VITA_ACT_NONE), st));
+        VITA_TRY(gemm_f32(lin(s.ones, 1, fw->h1_w, 1, nullptr, s.dAt, H, B, H, 1, VITA_ACT_NONE), st));
+        VITA_TRY(vita_act_bwd_f32(s.Ah, s.dAt, s.dSt, (int64_t)B * H, VITA_ACT_SILU, st));
+        vita_linear_args d = lin(s.dSt, H, fw->h2_w, H, nullptr, s.dtc_tan, H, B, H, H, VITA_ACT_NONE);
+        d.resid = s.dtc_tan; d.ld_resid = H;
+        VITA_TRY(gemm_f32(d, st));
+    }
+    // z_t = (1-t)*x1 + t*x0, v = x0 - x1: the CFM interpolation with the roles of the end points swapped
+    VITA_TRY(vita_cfm_interpolate_f32(z1, s.z0, t, nullptr, nullptr, mc.X0(0), s.v, B, D, st));
+    VITA_TRY(mf_trunk_fwd(mc, 0, s.tc, H));
+    VITA_TRY(gemm_f32(lin(mc.Xs(L, 0), H, fw->u_w, H, fw->u_b, s.u0, D, B, D, H, VITA_ACT_NONE), st));
+    VITA_TRY(mf_tangent_fwd(mc, s.v, s.dtc_tan));
+    const float pexp = 1.0f - cfg->adaptive_loss_gamma;
+    hipLaunchKernelGGL(mf_loss_rows_kernel, dim3((B + 3) / 4), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, B, D, pexp, cfg->adaptive_loss_c, s.rows, s.wrow);
+    hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.rows, B, losses + VITA_LOSS_FLOW);
+    VITA_CHECK_HIP(hipGetLastError());
+    // MeanFlow sampler with grad                                                  mean_flow_matcher.py:201-233
+    auto hstep = [&](int k) { return (float)((1.0 - (double)k / (double)K) - (1.0 - (double)(k + 1) / (double)K)); };
+    if (do_sample) {
+        VITA_CHECK_HIP(hipMemcpyAsync(mc.X0(1), s.z0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+        for (int k = 0; k < K; ++k) {
+            const int e = k + 1;
+            VITA_TRY(mf_trunk_fwd(mc, e, s.tc + (size_t)(B + k) * H, 0));
+            float* dst = (k == K - 1) ? pred : mc.X0(e + 1);
+            vita_linear_args o = lin(mc.Xs(L, e), H, fw->u_w, H, fw->u_b, dst, D, B, D, H, VITA_ACT_NONE);
+            o.use_gate_scalar = 1; o.gate_scalar = -hstep(k); o.resid = mc.X0(e); o.ld_resid = D;
+            VITA_TRY(gemm_f32(o, st));
+        }
+        if (do_cons) VITA_TRY(vita_mse_loss_fwd_f32(pred, z1, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_CONSISTENCY, st));
+    }
+    const Stack dec = stack_of(w->dec);
+    const int r0 = dec_pred ? 0 : B;
+    const int M = (dec_pred ? B : 0) + (dec_enc ? B : 0);
+    const int enc_row = dec_pred ? B : 0;
+    const int64_t n_rec = (int64_t)B * OUT;
+    if (M > 0) {
+        VITA_TRY(stack_fwd(dec, s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, st));
+        auto recon = cfg->recon_l1 ? vita_l1_loss_fwd_f32 : vita_mse_loss_fwd_f32;
+        if (dec_pred) VITA_TRY(recon(s.dec.out, actions, n_rec, s.loss_part, losses + VITA_LOSS_FLOW_RECON, st));
+        if (dec_enc) VITA_TRY(recon(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.loss_part, losses + VITA_LOSS_ENC_RECON, st));
+    }
+    const float wsum[5] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
+                           dec_enc ? cfg->enc_recon_weight : 0.f};
+    VITA_TRY(launch_weighted_sum(losses, wsum, 5, losses + VITA_LOSS_TOTAL, st));
+    if (!grads) return VITA_OK;
+
+    // ---- backward -----------------------------------------------------------------------------
+    const vita_meanflow_policy_weights& g = *grads;
+    const vita_meanflow_weights& gf = g.flow;
+    if (!dec_pred) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ, 0, (size_t)B * D * 4, st));
+    if (!dec_enc) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ + (size_t)B * D, 0, (size_t)B * D * 4, st));
+    if (M > 0) {
+        auto recon_bwd = cfg->recon_l1 ? vita_l1_loss_bwd_f32 : vita_mse_loss_bwd_f32;
+        if (dec_pred) VITA_TRY(recon_bwd(s.dec.out, actions, n_rec, s.consts + 2, s.dec.dOut, nullptr, 0, st));
+        if (dec_enc)
+            VITA_TRY(recon_bwd(s.dec.out + (size_t)enc_row * OUT, actions, n_rec, s.consts + 3, s.dec.dOut + (size_t)enc_row * OUT, nullptr, 0, st));
+        VITA_TRY(stack_bwd(dec, stack_of(g.dec), s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, s.dec.dOut, OUT, s.dZZ + (size_t)r0 * D, D,
+                           s.cs_part, st));
+    } else {
+        const Stack gd = stack_of(g.dec);
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.in_w), 0, (size_t)gd.TR * gd.IN * 4, st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.in_b), 0, (size_t)gd.TR * 4, st));
+        for (int i = 0; i < gd.NL; ++i) {
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc1_w[i]), 0, (size_t)gd.FF * gd.TR * 4, st));
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc1_b[i]), 0, (size_t)gd.FF * 4, st));
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc2_w[i]), 0, (size_t)gd.TR * gd.FF * 4, st));
+            VITA_CHECK_HIP(hipMemsetAsync(mut(gd.fc2_b[i]), 0, (size_t)gd.TR * 4, st));
+        }
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_w), 0, (size_t)gd.OUT * gd.TR * 4, st));
+        VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_b), 0, (size_t)gd.OUT * 4, st));
+    }
+    float* dpred = s.dZZ;
+    float* dz1 = s.dZZ + (size_t)B * D;
+    if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
+    // MeanFlow loss -> DU(0); primal chain of evaluation 0 -> d z_t
+    hipLaunchKernelGGL(mf_loss_bwd_kernel, dim3(mfgrid((int64_t)B * D)), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, s.wrow, B, D, mc.DU(0));
+    VITA_CHECK_HIP(hipGetLastError());
+    VITA_TRY(mf_chain_bwd(mc, 0, s.dzt, D, nullptr, 0));
+    // conditioning gradients, eval 0: per row, dtc[b] = DX(0,0)[b] - DX(L,0)[b]  (sum over layers of d x_cond telescopes)
+    hipLaunchKernelGGL(mf_sub_kernel, dim3(mfgrid((int64_t)B * H)), dim3(MFT), 0, st, mc.DX(0, 0), mc.DX(L, 0), s.dtc, (int64_t)B * H);
+    VITA_CHECK_HIP(hipGetLastError());
+    if (do_sample) {
+        const float* dxn = dpred;
+        for (int k = K - 1; k >= 0; --k) {
+            const int e = k + 1;
+            VITA_TRY(vita_gate_bwd_f32(dxn, nullptr, nullptr, 0, -hstep(k), mc.DU(e), nullptr, 0, B, D, st));
+            float* dst = (k == 0) ? s.dz0 : ((k & 1) ? s.dxa : s.dxb);
+            VITA_TRY(mf_chain_bwd(mc, e, dst, D, dxn, D));
+            hipLaunchKernelGGL(mf_sub_kernel, dim3(mfgrid((int64_t)B * H)), dim3(MFT), 0, st, mc.DX(0, e), mc.DX(L, e), s.dtmp, (int64_t)B * H);
+            VITA_CHECK_HIP(hipGetLastError());
+            VITA_TRY(vita_colsum_f32(s.dtmp, H, B, H, s.cs_part, s.dtc + (size_t)(B + k) * H, 0, st));
+            dxn = dst;
+        }
+    } else {
+        VITA_CHECK_HIP(hipMemsetAsync(s.dz0, 0, (size_t)B * D * 4, st));
+    }
+    // z_t = t*x0 + (1-t)*x1 (v is detached): d x1 += (1-t) d z_t, d x0 += t d z_t
+    VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dzt, nullptr, t, nullptr, nullptr, dz1, s.dz0, B, D, 1, st));
+    // weight gradients over the stacked E*B rows
+    {
+        const int R = E * B;
+        VITA_TRY(gemm_f32(wgrad(s.DU, D, mc.Xs(L, 0), H, mut(gf.u_w), H, R, H, D), st));
+        VITA_TRY(vita_colsum_f32(s.DU, D, R, D, s.cs_part, mut(gf.u_b), 0, st));
+        for (int l = 0; l < L; ++l) {
+            VITA_TRY(gemm_f32(wgrad(mc.DX(l + 1, 0), H, mc.S(l, 0), FF, mut(gf.fc2_w[l]), FF, R, FF, H), st));
+            VITA_TRY(vita_colsum_f32(mc.DX(l + 1, 0), H, R, H, s.cs_part, mut(gf.fc2_b[l]), 0, st));
+            VITA_TRY(gemm_f32(wgrad(mc.U1(l, 0), FF, mc.Xc(l, 0), H, mut(gf.fc1_w[l]), H, R, H, FF), st));
+            VITA_TRY(vita_colsum_f32(mc.U1(l, 0), FF, R, FF, s.cs_part, mut(gf.fc1_b[l]), 0, st));
+        }
+        VITA_TRY(gemm_f32(wgrad(mc.DX(0, 0), H, s.X0, D, mut(gf.in_w), D, R, D, H), st));
+        VITA_TRY(vita_colsum_f32(mc.DX(0, 0), H, R, H, s.cs_part, mut(gf.in_b), 0, st));
+        if (gf.v_w) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_w), 0, (size_t)D * H * 4, st));    // the v head takes no part (use_imf = False)
+        if (gf.v_b) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_b), 0, (size_t)D * 4, st));
+    }
+    // conditioning path: tc = t2(silu(t1 t)) + h2(silu(h1 h)) over the T rows
+    {
+        struct Br { const float *in, *A, *Sx, *w1, *w2; const float *gw1, *gb1, *gw2, *gb2; };
+        const Br brs[2] = {{s.tv, s.At, s.St, fw->t1_w, fw->t2_w, gf.t1_w, gf.t1_b, gf.t2_w, gf.t2_b},
+                           {s.hv, s.Ah, s.Sh, fw->h1_w, fw->h2_w, gf.h1_w, gf.h1_b, gf.h2_w, gf.h2_b}};
+        for (const Br& b : brs) {
+            VITA_TRY(gemm_f32(wgrad(s.dtc, H, b.Sx, H, mut(b.gw2), H, T, H, H), st));
+            VITA_TRY(vita_colsum_f32(s.dtc, H, T, H, s.cs_part, mut(b.gb2), 0, st));
+            vita_linear_args a = dgrad(s.dtc, H, b.w2, H, s.dA1, H, T, H, H);
+            a.act = VITA_ACT_SILU; a.act_grad_z = b.A; a.ld_act_grad_z = H;
+            VITA_TRY(gemm_f32(a, st));
+            VITA_TRY(gemm_f32(wgrad(s.dA1, H, b.in, 1, mut(b.gw1), 1, T, 1, H), st));
+            VITA_TRY(vita_colsum_f32(s.dA1, H, T, H, s.cs_part, mut(b.gb1), 0, st));
+        }
+    }
+    // encoders
+    {
+        StepWs es{};
+        es.senc = s.senc; es.cnn = s.cnn;
+        if (w->enc.kind == VITA_ENC_SIMPLE)
+            VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
+                               w->enc.C, nullptr, 0, s.cs_part, st));
+        else
+            VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, dz1, D, B, s.cs_part, st));
+    }
+    VITA_TRY(gemm_f32(wgrad(s.dz0, D, obs_features, ldobs, mut(g.obs_w), w->O, B, w->O, D), st));
+    VITA_TRY(vita_colsum_f32(s.dz0, D, B, D, s.cs_part, mut(g.obs_b), 0, st));
+    return VITA_OK;
+}
+
+}  // extern "C"

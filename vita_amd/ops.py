@@ -304,11 +304,14 @@ def consistency_sample(fw: FlowNetHandle, x0: Tensor, num_steps: int, eps: float
 class MeanFlowNetHandle:
     """vita_meanflow_weights over a state dict with SimpleMeanFlowNet's keys (simple_mean_flow_net.py:20-47)."""
 
-    def __init__(self, sd: Mapping[str, Tensor], device, prefix: str = "flow_net."):
+    def __init__(self, sd: Mapping[str, Tensor], device, prefix: str = "flow_net.", strict: bool = False, into=None):
         device = torch.device(device)
         self.t = {}
-        g = lambda k: self.t.setdefault(k, _prep(sd, prefix + k, device))  # noqa: E731
-        w = L.MeanFlowWeights()
+        if strict:      # the tensors themselves (contiguous fp32 on the GPU): what a gradient descriptor needs
+            g = lambda k: self.t.setdefault(k, _dev_f32(sd, prefix + k, device, True))  # noqa: E731
+        else:
+            g = lambda k: self.t.setdefault(k, _prep(sd, prefix + k, device))  # noqa: E731
+        w = into if into is not None else L.MeanFlowWeights()
         iw = g("input_layer.weight")
         w.H, w.D = iw.shape
         n = 0
@@ -894,6 +897,63 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
                                       dobs.data_ptr() if dobs is not None else None, pw.O, ev, ws.data_ptr(), ws.numel(),
                                       _stream(obs_features)), "vita_compute_loss_f32")
     return losses, dobs
+
+
+class MeanFlowPolicyHandle:
+    """vita_meanflow_policy_weights over a state dict whose flow_net.* keys are SimpleMeanFlowNet's (policy.flow_net.name:
+    simple_mean_flow_net); the other modules as in PolicyHandle."""
+
+    def __init__(self, sd: Mapping[str, Tensor], device, pred_horizon: int = 16, strict: bool = False):
+        device = torch.device(device)
+        self.device = device
+        self.t = {}
+        g = lambda k: self.t.setdefault(k, _dev_f32(sd, k, device, strict))  # noqa: E731
+        w = L.MeanFlowPolicyWeights()
+        ow = g("obs_encoder.weight")
+        w.O = ow.shape[1]
+        w.obs_w, w.obs_b = ow.data_ptr(), g("obs_encoder.bias").data_ptr()
+        self.flow = MeanFlowNetHandle(sd, device, "flow_net.", strict=strict, into=w.flow)
+        _fill_dec(w.dec, g, "action_decoder.", sd)
+        _fill_enc(w.enc, g, "action_encoder.", sd, pred_horizon, ow.shape[0])
+        self.w = w
+        self.O, self.D, self.T, self.A, self.OUT = w.O, w.flow.D, w.enc.T, w.enc.A, w.dec.OUT
+
+
+def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
+                         enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, adaptive_loss_gamma: float = 0.5,
+                         adaptive_loss_c: float = 1e-3) -> "L.MeanFlowLossConfig":
+    if recon not in ("l1", "l2"):
+        raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")
+    c = L.MeanFlowLossConfig()
+    c.num_steps, c.recon_l1, c.decode_flow_latents = num_steps, int(recon == "l1"), int(decode_flow_latents)
+    c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
+    c.adaptive_loss_gamma, c.adaptive_loss_c = adaptive_loss_gamma, adaptive_loss_c
+    return c
+
+
+def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, r: Tensor, *,
+                          grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None) -> Tensor:
+    """VitaPolicy.compute_loss with the MeanFlow matcher (+ backward when `grads` is given): vita_compute_loss_meanflow_f32.
+    Returns losses (8,) indexed as _lib.LOSS_NAMES with index 1 = meanflow_loss.  No host sync."""
+    lib = L.load()
+    obs_features = _rows(obs_features, "compute_loss_meanflow: obs_features")
+    actions = _f32(actions, "compute_loss_meanflow: actions").contiguous()
+    t = _f32(t, "compute_loss_meanflow: t").contiguous()
+    r = _f32(r, "compute_loss_meanflow: r").contiguous()
+    B = obs_features.shape[0]
+    if obs_features.shape[1] != pw.O or tuple(actions.shape) != (B, pw.T, pw.A) or tuple(t.shape) != (B,) or tuple(r.shape) != (B,):
+        raise L.VitaHipError(f"compute_loss_meanflow: obs {tuple(obs_features.shape)} / actions {tuple(actions.shape)} / t {tuple(t.shape)} / "
+                             f"r {tuple(r.shape)} do not match O={pw.O}, T={pw.T}, A={pw.A}")
+    dev = obs_features.device
+    if losses is None:
+        losses = torch.empty(L.LOSS_COUNT, dtype=torch.float32, device=dev)
+    nbytes = lib.vita_compute_loss_meanflow_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
+    ws = workspace(dev, nbytes)
+    L.check(lib.vita_compute_loss_meanflow_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
+                                               obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(), r.data_ptr(),
+                                               B, losses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(obs_features)),
+            "vita_compute_loss_meanflow_f32")
+    return losses
 
 
 def action_encoder_forward(pw: PolicyHandle, actions: Tensor) -> Tensor:
