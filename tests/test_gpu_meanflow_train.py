@@ -108,3 +108,51 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
             assert grads[k].abs().max().item() == 0, f"{variant}: grad {k} should be zero"
         else:
             assert nerr(grads[k], gr) <= 2e-5, f"{variant}: grad {k} {nerr(grads[k], gr):g}"
+
+
+def test_policy_mean_matcher_trains(dev):
+    """policy.flow_matcher.name = mean + flow_net.name = simple_mean_flow_net through VitaPolicy.compute_loss (explicit t, r vs
+    the oracle in fp64, metric keys as the reference emits them, .backward()) and PolicyTrainer; improved_mean stays
+    sampler-only."""
+    from test_gpu_policy import small_cfg, make_policy, make_batch, hot_sd, oracle_features
+    from vita_amd.trainer import PolicyTrainer
+    cfg = small_cfg("cnn", matcher="mean")
+    cfg.policy.flow_net.name = "simple_mean_flow_net"
+    cfg.policy.flow_matcher.num_sampling_steps = 1
+    pol = make_policy(cfg, seed=2)
+    with torch.no_grad():      # the reference zero-initialises the MeanFlow heads: give them values
+        for k, p in pol.named_parameters():
+            if "output_layer" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(3)))
+    pol = pol.to(dev)
+    g = torch.Generator().manual_seed(4)
+    B = 11
+    batch = make_batch(cfg, B, g)
+    smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
+    t, r = smp.max(1)[0], smp.min(1)[0]
+    r[:4] = t[:4]
+    feats, acts = oracle_features(pol, batch, cfg)
+    sd64 = {k: v.double() for k, v in hot_sd(pol).items()}
+    ref, m = O.compute_loss_meanflow(sd64, feats.double(), acts.double(), t.double(), r.double(), 1)
+    nb = pol.normalize_targets(pol.normalize_inputs({k: v.to(dev) for k, v in batch.items()}))
+    pol.train()
+    loss, met = pol.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev))
+    assert set(met) == set(m), (sorted(met), sorted(m))
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item()) and abs(met["meanflow_loss"] - m["meanflow_loss"].item()) <= 1e-5 * abs(m["meanflow_loss"].item())
+    loss.backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for _, p in pol.hot_path_named_parameters())
+    tr = PolicyTrainer(cfg, pol, dev, num_training_steps=20)
+    first = None
+    for _ in range(10):
+        tr.train_step(batch, t=t.to(dev), pair_i=r.to(dev))
+        mm = tr.metrics()
+        first = first if first is not None else mm["loss"]
+    assert mm["loss"] < first and all(v == v for v in mm.values()), (first, mm)
+    torch.manual_seed(0)
+    tr.train_step(batch)        # the matcher's own (t, r) draw
+    assert tr.metrics()["loss"] == tr.metrics()["loss"]
+    cfg2 = small_cfg("cnn", matcher="improved_mean")
+    cfg2.policy.flow_net.name = "simple_mean_flow_net"
+    pol2 = make_policy(cfg2, seed=2).to(dev)
+    with pytest.raises(NotImplementedError):
+        pol2.compute_loss(nb)

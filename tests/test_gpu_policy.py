@@ -252,7 +252,7 @@ def test_freeze_flags_and_contrastive_terms_at_policy_level():
 @pytest.mark.parametrize("matcher", ["mean", "consistency"])
 def test_alternate_matchers_generate_actions(matcher):
     """policy.flow_matcher.name = mean / consistency (vita_policy.py:53,84-97): generate_actions runs obs_encoder -> the
-    matcher's sampler -> decoder on the HIP path and matches the oracle; training raises (not built)."""
+    matcher's sampler -> decoder on the HIP path and matches the oracle (MeanFlow training: tests/test_gpu_meanflow_train.py)."""
     cfg = small_cfg(matcher=matcher)
     if matcher == "mean":
         cfg.policy.flow_net.name = "simple_mean_flow_net"
@@ -277,8 +277,9 @@ def test_alternate_matchers_generate_actions(matcher):
     z = O.mean_flow_sample(sd, z0, 1) if matcher == "mean" else O.consistency_sample(sd, z0, 3, sigma_var=0.0)
     ref = O.simple_action_decode(sd, z, cfg.policy.pred_horizon, cfg.task.action_dim)
     assert acts.shape == ref.shape and nerr(acts, ref) <= 1e-5
-    with pytest.raises(NotImplementedError):
-        pol.compute_loss(nb)
+    if matcher == "consistency":    # its training loss is not built (and cannot run on 2-D latents in the reference either)
+        with pytest.raises(NotImplementedError):
+            pol.compute_loss(nb)
     if matcher == "consistency":   # default sigma_var = 1.0: stochastic sampler, finite and different from the ODE branch
         cfg2 = small_cfg(matcher=matcher)
         cfg2.policy.flow_matcher.pop("sigma")

@@ -121,7 +121,11 @@ def test_flow_matcher_table():
         get_flow_matcher("schrodinger", sigma=0.0)       # vita.yaml's sigma: 0.0 is rejected by torchcfm's bridge matcher too
     # sampler-only matchers: constructor arguments as in the reference, training refused
     m = get_flow_matcher("mean", sigma=0.0, num_sampling_steps=1, flow_ratio=0.25)          # MeanFlow swallows **kwargs (:56)
-    assert m.inference_only and m.flow_ratio == 0.25 and not m.use_imf and get_flow_matcher("improved_mean").use_imf
+    assert not m.inference_only and m.flow_ratio == 0.25 and not m.use_imf      # MeanFlow training is built (fused MeanFlow step)
+    im = get_flow_matcher("improved_mean")
+    assert im.use_imf and im.inference_only and get_flow_matcher("mean", dispersive_loss_weight=0.1).inference_only
+    tt, rr = m.sample_t_r(64, "cpu")                                                          # mean_flow_matcher.py:87-107
+    assert tt.shape == (64,) and bool((tt >= rr).all()) and int((tt == rr).sum()) >= 16 and float(tt.max()) < 1 and float(rr.min()) > 0
     with pytest.raises(NotImplementedError):
         m.compute_loss(None, torch.zeros(2, 4))
     with pytest.raises(ValueError):

@@ -172,3 +172,25 @@ def test_vae_branch_losses_and_gradients_match_reference_autograd(golden_dir):
         gs = torch.autograd.grad(loss, [sdg[k] for k in keys])
         for k, g in zip(keys, gs):
             close(g, v[f"{tag}/{name}/grad/{k}"], 2e-5)
+
+
+def test_meanflow_training_losses_and_gradients_match_reference_autograd(golden_dir):
+    """MeanFlow training (mean_flow_matcher.py:109-199 inside vita_policy.py:112-189): the oracle against the losses and
+    gradients of the reference's own MeanFlowMatcher / SimpleMeanFlowNet / encoder / decoder + autograd
+    (tools/gen_golden_meanflow.py), K = 1 and 3 sampler steps."""
+    v = load(os.path.join(golden_dir, "meanflow_train.safetensors"))
+    sd = {k[len("mf/sd/"):]: x for k, x in v.items() if k.startswith("mf/sd/")}
+    obs, actions, t, r = (v["mf/" + k] for k in ("obs_features", "actions", "t", "r"))
+    for K in (1, 3):
+        sdg = {k: x.clone().requires_grad_(True) for k, x in sd.items()}
+        loss, m = O.compute_loss_meanflow(sdg, obs, actions, t, r, K)
+        for k in m:
+            close(m[k].detach().reshape(1), v[f"mf/K{K}/loss/{k}"], 3e-6)
+        keys = list(sdg)
+        gs = torch.autograd.grad(loss, [sdg[k] for k in keys], allow_unused=True)
+        for k, g in zip(keys, gs):
+            ref = v[f"mf/K{K}/grad/{k}"]
+            if g is None:
+                assert ref.abs().max().item() == 0.0, k        # the v head takes no part without use_imf
+            else:
+                close(g, ref, 2e-5)

@@ -150,8 +150,25 @@ class _InferenceOnlyMatcher:
 
 class MeanFlowMatcher(_InferenceOnlyMatcher):
     """flow/mean_flow_matcher.py:42-233 — constructor arguments kept; `.sample` is ONE C-ABI call over a
-    `vita_amd.ops.MeanFlowNetHandle` (SimpleMeanFlowNet).  `.compute_loss` (JVP through the net with create_graph,
-    logit-normal (t, r) sampling, adaptive / dispersive losses, :109-199) is not built."""
+    `vita_amd.ops.MeanFlowNetHandle` (SimpleMeanFlowNet).  Training: the MeanFlow loss (use_imf = False, dispersive weight 0:
+    JVP target, adaptive L2 loss, :109-183) runs inside the policy's fused MeanFlow step (vita_compute_loss_meanflow_f32) with
+    the (t, r) draw of `sample_t_r` made here on the host as in the reference; improved MeanFlow (use_imf) and the dispersive
+    term are not built."""
+
+    @property
+    def inference_only(self) -> bool:
+        return bool(self.use_imf) or float(self.dispersive_loss_weight) > 0.0
+
+    def sample_t_r(self, batch_size, device):
+        """mean_flow_matcher.py:87-107, statement for statement (torch's generators, as in the reference)."""
+        normal_samples = torch.randn(batch_size, 2, device=device) * self.time_dist_sigma + self.time_dist_mu
+        samples = torch.sigmoid(normal_samples)
+        t = torch.max(samples, dim=1)[0]
+        r = torch.min(samples, dim=1)[0]
+        num_selected = int(self.flow_ratio * batch_size)
+        indices = torch.randperm(batch_size, device=device)[:num_selected]
+        r[indices] = t[indices]
+        return t, r
 
     def __init__(self, flow_ratio=0.5, time_dist_mu=-0.4, time_dist_sigma=1.0, adaptive_loss_gamma=0.5, norm_p=1.0, norm_eps=0.01,
                  aux_v_loss_weight=1.0, dispersive_loss_tau=1.0, dispersive_loss_weight=0.0, cfg_scale=0.5, use_imf=False, **kwargs):
@@ -162,8 +179,8 @@ class MeanFlowMatcher(_InferenceOnlyMatcher):
         self.num_sampling_steps = 1
 
     def compute_loss(self, model, target, start=None, **kwargs):
-        raise NotImplementedError("MeanFlow training (mean_flow_matcher.py:109-199: jvp with create_graph, adaptive and dispersive "
-                                  "losses) is not built; only MeanFlowMatcher.sample runs on the HIP path")
+        raise NotImplementedError("MeanFlowMatcher.compute_loss on its own is not exposed: the MeanFlow loss runs inside "
+                                  "VitaPolicy.compute_loss (vita_compute_loss_meanflow_f32); improved MeanFlow / the dispersive term are not built")
 
     def sample(self, model: "ops.MeanFlowNetHandle", shape, device, num_steps=None, return_traces=False, start=None, **kwargs):
         """mean_flow_matcher.py:201-233."""

@@ -222,6 +222,22 @@ class _FusedLoss(torch.autograd.Function):
         return (None, dobs, None, None, None, None, None, None) + grads
 
 
+class _FusedMeanFlowLoss(torch.autograd.Function):
+    """_FusedLoss for flow_matcher.name = 'mean': vita_compute_loss_meanflow_f32 (forward + backward in one call)."""
+
+    @staticmethod
+    def forward(ctx, policy, obs_features, actions, t, r, *params):
+        pw, gw, gsd = policy._train_handles(stage=True)
+        losses = ops.compute_loss_meanflow(pw, policy._mf_cfg, obs_features.detach(), actions, t, r, grads=gw)
+        ctx.staged = [gsd[k] for k, _ in policy.hot_path_named_parameters()]
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), losses
+
+    @staticmethod
+    def backward(ctx, gout, _):
+        return (None, None, None, None, None) + tuple(g * gout for g in ctx.staged)
+
+
 class VitaPolicy(nn.Module):
     """flare/policies/vita/vita_policy.py:36-283 + base_policy.py:15-89."""
 
@@ -276,6 +292,7 @@ class VitaPolicy(nn.Module):
         # alternate matchers (mean / improved_mean / consistency): sampler only, see flow.py
         self.inference_only = bool(getattr(self.FM, "inference_only", False))
         self.mean_flow = fn.name == MEAN_FLOW_NET_NAME
+        self._mf_cfg = None
         if self.mean_flow != isinstance(self.FM, MeanFlowMatcher):
             raise ValueError("flow_net 'simple_mean_flow_net' goes with the 'mean' / 'improved_mean' flow matchers, and only with them")
         if self.mean_flow:
@@ -300,6 +317,20 @@ class VitaPolicy(nn.Module):
                                          kl_weight=float(self.action_kl_weight) if self.use_action_vae else 0.0,
                                          gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype],
                                          fm_kind=int(self.FM.kind), fm_sigma=float(self.FM.sigma))
+        if self.mean_flow and not self.inference_only:      # MeanFlow training: the fused MeanFlow step's branches
+            bad = [n for n, on in (("action_ae.use_variational", self.use_action_vae), ("action_ae.freeze_encoder", self.freeze_action_encoder),
+                                   ("action_ae.freeze_decoder", self.freeze_action_decoder),
+                                   ("vita.enc_contrastive_weight", self.enc_contrastive_weight > 0),
+                                   ("vita.flow_contrastive_weight", self.flow_contrastive_weight > 0)) if on]
+            if bad:
+                self.inference_only = True      # sampler only; compute_loss raises and names the reason
+                self._mf_unsupported = bad
+            self._mf_cfg = ops.meanflow_loss_config(num_steps=self.num_sampling_steps, recon=ae.recon_loss_type,
+                                                    decode_flow_latents=bool(pol.vita.decode_flow_latents),
+                                                    consistency_weight=float(pol.vita.consistency_weight),
+                                                    enc_recon_weight=float(self.enc_action_recon_weight),
+                                                    flow_recon_weight=float(self.flow_action_recon_weight),
+                                                    adaptive_loss_gamma=float(self.FM.adaptive_loss_gamma))
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -406,8 +437,8 @@ class VitaPolicy(nn.Module):
             else:
                 gsd = {k: torch.zeros_like(p.data) for k, p in named}
             dev = self.obs_encoder.weight.device
-            c = (self._key(), ops.PolicyHandle(sd, dev, self.pred_horizon, strict=True),
-                 ops.PolicyHandle(gsd, dev, self.pred_horizon, strict=True), gsd)
+            handle = ops.MeanFlowPolicyHandle if self.mean_flow else ops.PolicyHandle
+            c = (self._key(), handle(sd, dev, self.pred_horizon, strict=True), handle(gsd, dev, self.pred_horizon, strict=True), gsd)
             self._cache[slot] = c
         return c[1], c[2], c[3]
 
@@ -464,12 +495,22 @@ class VitaPolicy(nn.Module):
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
-        t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
-                                                            actions, enc_noise, fm_noise)
         pw, gw, gsd = self._train_handles()
         if self._flat_grad is None:
             for (k, p) in self.hot_path_named_parameters():
                 p.grad = gsd[k]
+        if self.mean_flow:      # (t, r) of MeanFlowMatcher.sample_t_r; `pair_i` carries an explicit r
+            if t is None:
+                t, r = self.FM.sample_t_r(obs_features.shape[0], obs_features.device)
+            else:
+                r = pair_i if pair_i is not None else t
+            out = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r.to(torch.float32), grads=gw, losses=losses)
+            for e in (grad_ready_events or ()):     # the MeanFlow step records no intermediate events: every bucket is ready at its end
+                if e is not None:
+                    e.record(torch.cuda.current_stream(obs_features.device))
+            return out
+        t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
+                                                            actions, enc_noise, fm_noise)
         out, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
                                   grad_ready_events=grad_ready_events, losses=losses, enc_noise=enc_noise, fm_noise=fm_noise)
         return out
@@ -483,6 +524,8 @@ class VitaPolicy(nn.Module):
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
+        if self.mean_flow:
+            return self._compute_loss_meanflow(obs_features, actions, t, pair_i)
         t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
                                                             actions, enc_noise, fm_noise)
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
@@ -512,12 +555,38 @@ class VitaPolicy(nn.Module):
             metrics["enc_action_recon_loss"] = vals[4]
         return loss, metrics
 
+    def _compute_loss_meanflow(self, obs_features, actions, t=None, r=None):
+        """compute_loss for flow_matcher.name = 'mean' (mean_flow_matcher.py:109-199 inside vita_policy.py:112-189); metric keys
+        as the reference emits them: FM's {'meanflow_loss', 'loss'} plus the policy's."""
+        if t is None:
+            t, r = self.FM.sample_t_r(obs_features.shape[0], obs_features.device)
+        elif r is None:
+            r = t
+        if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
+            params = [p for _, p in self.hot_path_named_parameters()]
+            loss, losses = _FusedMeanFlowLoss.apply(self, obs_features, actions, t, r, *params)
+        else:
+            pw, _, _ = self._train_handles()
+            losses = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r)
+            loss = losses[0]
+        vals = losses.detach().cpu().tolist()
+        metrics = {"meanflow_loss": vals[1], "loss": vals[1], "flow_loss": vals[1]}
+        cfgv = self.config.policy.vita
+        if cfgv.decode_flow_latents:
+            if cfgv.consistency_weight > 0:
+                metrics["consistency_loss"] = vals[2]
+            if self.flow_action_recon_weight > 0:
+                metrics["flow_action_recon_loss"] = vals[3]
+        if self.enc_action_recon_weight > 0:
+            metrics["enc_action_recon_loss"] = vals[4]
+        return loss, metrics
+
     @torch.no_grad()
     def generate_actions(self, batch):
         """vita_policy.py:191-208: observer features -> obs_encoder -> K Euler steps -> decoder, one C-ABI call."""
         obs_features = self.observer(batch)
         fw, dw, _ = self._infer_handles()
-        if self.inference_only:   # mean / improved_mean / consistency: obs_encoder -> FM.sample -> decoder, three C-ABI calls
+        if self.inference_only or self.mean_flow:   # mean / improved_mean / consistency: obs_encoder -> FM.sample -> decoder, three C-ABI calls
             z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
             z = self.FM.sample(fw, shape=tuple(z0.shape), device=z0.device, start=z0, num_steps=self.num_sampling_steps)
             return ops.decoder_forward(dw, z).view(-1, self.pred_horizon, self.action_dim)
