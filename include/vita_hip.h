@@ -461,9 +461,10 @@ int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, in
  * (vita_policy.py:112-189) with MeanFlowMatcher.compute_loss (flow/mean_flow_matcher.py:109-199, use_imf = False,
  * dispersive_loss_weight = 0) and the MeanFlow sampler with grad (:201-233), forward + backward in one call.
  *   t, r (B): the (t, r) draw of sample_t_r (:87-107), made by the caller.
- *   losses: device float[VITA_LOSS_COUNT]; VITA_LOSS_FLOW holds meanflow_loss, the other entries as in vita_compute_loss_f32.
- *   grads: NULL = forward only; else every gradient buffer is overwritten (the v head's with zeros: it takes no part).
- * Not built here: improved MeanFlow (use_imf), the dispersive term, the variational encoder, freeze flags, contrastive terms. */
+ *   losses: device float[VITA_MF_LOSS_COUNT], indexed by VITA_MF_LOSS_*.
+ *   grads: NULL = forward only; else every gradient buffer is overwritten (without use_imf the v head's with zeros: it takes no part).
+ * use_imf = 1 is improved MeanFlow (flow_matcher.name = "improved_mean", :137-163).
+ * Not built here: the dispersive term, the variational encoder, freeze flags, contrastive terms. */
 typedef struct vita_meanflow_policy_weights {
     int32_t O;
     const float *obs_w, *obs_b;
@@ -476,7 +477,15 @@ typedef struct vita_meanflow_loss_config {
     float consistency_weight, enc_recon_weight, flow_recon_weight;
     float adaptive_loss_gamma;   /* MeanFlowMatcher(adaptive_loss_gamma=0.5) */
     float adaptive_loss_c;       /* adaptive_l2_loss(c=1e-3), mean_flow_matcher.py:10 */
+    int32_t use_imf;             /* improved MeanFlow (:137-163): tangent dz = the v head's no-grad prediction at (z_t, t, h = 0),
+                                    compound = u + h*stopgrad(dudt) against v, plus the auxiliary v-head loss */
+    float norm_p, norm_eps;      /* adaptive_imf_loss (:21-24): per-sample sum of squares / stopgrad((that + norm_eps)^norm_p) */
+    float aux_v_loss_weight;
 } vita_meanflow_loss_config;
+/* losses of the MeanFlow step: device float[VITA_MF_LOSS_COUNT] */
+enum { VITA_MF_LOSS_TOTAL = 0, VITA_MF_LOSS_FLOW = 1 /* meanflow_loss, or imf_loss + aux_v_loss_weight * aux_v_loss */,
+       VITA_MF_LOSS_CONSISTENCY = 2, VITA_MF_LOSS_FLOW_RECON = 3, VITA_MF_LOSS_ENC_RECON = 4, VITA_MF_LOSS_IMF = 5, VITA_MF_LOSS_AUX_V = 6,
+       VITA_MF_LOSS_IMF_MSE = 7, VITA_MF_LOSS_AUX_V_MSE = 8, VITA_MF_LOSS_COUNT = 12 };
 size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_weights* w, const vita_meanflow_loss_config* cfg, int32_t B);
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,

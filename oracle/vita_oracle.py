@@ -359,6 +359,37 @@ def mean_flow_sample(sd: SD, start: Tensor, num_steps: int = 1, prefix: str = "f
     return x
 
 
+def improved_mean_flow_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, r: Tensor, norm_p: float = 1.0, norm_eps: float = 0.01,
+                            aux_v_loss_weight: float = 1.0, prefix: str = "flow_net."):
+    """MeanFlowMatcher.compute_loss with use_imf = True, mean_flow_matcher.py:137-163 (adaptive_imf_loss :21-24).
+    Returns (loss, metrics)."""
+    x1, x0 = target, start
+    t_ = t.view(-1, *([1] * (x0.dim() - 1)))
+    h_ = (t - r).view(-1, *([1] * (x0.dim() - 1)))
+    z_t = (1 - t_) * x1 + t_ * x0
+    v = x0 - x1
+    with torch.no_grad():                                                         # :138-140
+        v_net = mean_flow_net_forward(sd, z_t, t, t - t, prefix)[1]
+
+    def pred_imf(z_in, t_in, r_in):
+        u_, v_, _ = mean_flow_net_forward(sd, z_in, t_in, t_in - r_in, prefix)
+        return u_, v_
+
+    (u, v_pred), (dudt, _) = torch.autograd.functional.jvp(pred_imf, (z_t, t, r), (v_net, torch.ones_like(t), torch.zeros_like(r)),
+                                                          create_graph=True)     # :146-151
+    compound = u + h_ * dudt.detach()
+
+    def adaptive_imf(error):
+        per_sample = torch.sum(error ** 2, dim=tuple(range(1, error.ndim)))
+        return (per_sample / (per_sample + norm_eps).pow(norm_p).detach()).mean()
+
+    imf_loss = adaptive_imf(compound - v.detach())
+    aux_v_loss = adaptive_imf(v_pred - v.detach())
+    loss = imf_loss + aux_v_loss_weight * aux_v_loss
+    return loss, {"imf_loss": imf_loss, "aux_v_loss": aux_v_loss, "imf_mse": torch.mean((compound - v) ** 2),
+                  "aux_v_mse": torch.mean((v_pred - v) ** 2)}
+
+
 def mean_flow_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, r: Tensor, adaptive_loss_gamma: float = 0.5,
                    c: float = 1e-3, prefix: str = "flow_net.") -> Tensor:
     """MeanFlowMatcher.compute_loss, mean_flow_matcher.py:109-183 with use_imf = False and dispersive_loss_weight = 0;
@@ -396,7 +427,8 @@ def mean_flow_sample_grad(sd: SD, start: Tensor, num_steps: int = 1, prefix: str
 
 def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, r: Tensor, num_steps: int = 1,
                           consistency_weight: float = 1.0, enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5,
-                          recon_loss_type: str = "l1", decode_flow_latents: bool = True, adaptive_loss_gamma: float = 0.5):
+                          recon_loss_type: str = "l1", decode_flow_latents: bool = True, adaptive_loss_gamma: float = 0.5,
+                          use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01, aux_v_loss_weight: float = 1.0):
     """VitaPolicy.compute_loss (vita_policy.py:112-189) with flow_matcher.name = 'mean' over SimpleMeanFlowNet: defaults
     otherwise (plain autoencoder, nothing frozen, no contrastive terms).  Returns (loss, metrics of 0-dim tensors)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
@@ -404,9 +436,13 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
     m = {}
     obs_latents = obs_encode(sd, obs_features)
     action_latents = action_encode(sd, gt_actions)
-    flow_loss = mean_flow_loss(sd, obs_latents, action_latents, t, r, adaptive_loss_gamma)        # :126-130
+    if use_imf:
+        flow_loss, fm = improved_mean_flow_loss(sd, obs_latents, action_latents, t, r, norm_p, norm_eps, aux_v_loss_weight)
+        m.update(fm)
+    else:
+        flow_loss = mean_flow_loss(sd, obs_latents, action_latents, t, r, adaptive_loss_gamma)    # :126-130
+        m["meanflow_loss"] = flow_loss
     loss = flow_loss
-    m["meanflow_loss"] = flow_loss
     m["flow_loss"] = flow_loss
     if decode_flow_latents:                                                                        # :153-178
         pred = mean_flow_sample_grad(sd, obs_latents, num_steps)

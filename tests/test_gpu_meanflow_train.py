@@ -53,18 +53,22 @@ def run(ops, dev, sd, obs, actions, t, r, cfg):
 
 
 KEYS = {"loss": 0, "meanflow_loss": 1, "consistency_loss": 2, "flow_action_recon_loss": 3, "enc_action_recon_loss": 4}
+IMF_KEYS = {"loss": 0, "flow_loss": 1, "consistency_loss": 2, "flow_action_recon_loss": 3, "enc_action_recon_loss": 4, "imf_loss": 5,
+            "aux_v_loss": 6, "imf_mse": 7, "aux_v_mse": 8}
 
 
-@pytest.mark.parametrize("K", [1, 3])
-def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K):
+@pytest.mark.parametrize("K,use_imf", [(1, False), (3, False), (1, True), (2, True)])
+def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf):
+    """mean (use_imf False) and improved_mean (use_imf True, mean_flow_matcher.py:137-163) against the reference's autograd."""
+    tag = f"mf/{'imf_' if use_imf else ''}K{K}"
     sd = {k[len("mf/sd/"):]: v for k, v in gold.items() if k.startswith("mf/sd/")}
     obs, actions, t, r = (gold["mf/" + k] for k in ("obs_features", "actions", "t", "r"))
-    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K))
-    for k, i in KEYS.items():
-        ref = gold[f"mf/K{K}/loss/{k}"].item()
-        assert abs(losses[i].item() - ref) <= 1e-5 * abs(ref), f"K={K} {k}: {losses[i].item()} vs {ref}"
+    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, use_imf=use_imf))
+    for k, i in (IMF_KEYS if use_imf else KEYS).items():
+        ref = gold[f"{tag}/loss/{k}"].item()
+        assert abs(losses[i].item() - ref) <= 1e-5 * abs(ref), f"{tag} {k}: {losses[i].item()} vs {ref}"
     for k in sd:
-        ref = gold[f"mf/K{K}/grad/{k}"]
+        ref = gold[f"{tag}/grad/{k}"]
         assert torch.isfinite(grads[k]).all(), k
         if ref.abs().max().item() == 0:
             assert grads[k].abs().max().item() == 0, f"grad {k} should be zero"
@@ -72,11 +76,15 @@ def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K):
             assert nerr(grads[k], ref) <= 2e-5, f"K={K} grad {k}: {nerr(grads[k], ref):g}"
 
 
-@pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma"])
+@pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma", "imf_default_dims_b64", "imf_norm"])
 def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     g = torch.Generator().manual_seed(31)
     kw, ck = {}, {}
-    if variant == "default_dims_b64":
+    if variant.startswith("imf"):
+        kw.update(use_imf=True); ck.update(use_imf=True)
+    if variant == "imf_norm":
+        kw.update(norm_p=0.7, norm_eps=0.05, aux_v_loss_weight=0.3); ck.update(norm_p=0.7, norm_eps=0.05, aux_v_loss_weight=0.3)
+    if variant in ("default_dims_b64", "imf_default_dims_b64"):
         A, T, B, D, H, Lh, O_, enc, aeh, ael = 21, 16, 64, 512, 512, 4, 533, "cnn", 512, 4
     else:
         A, T, B, D, H, Lh, O_, enc, aeh, ael = 7, 16, 19, 64, 64, 3, 40, ("simple" if variant == "l2_simple_encoder" else "cnn"), 48, (2 if variant == "l2_simple_encoder" else 4)
@@ -102,7 +110,10 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     gs = torch.autograd.grad(loss, [sd64[k] for k in keys], allow_unused=True)
     losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, **ck))
     assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item()), (losses[0].item(), loss.item())
-    assert abs(losses[1].item() - m["meanflow_loss"].item()) <= 1e-5 * abs(m["meanflow_loss"].item())
+    assert abs(losses[1].item() - m["flow_loss"].item()) <= 1e-5 * abs(m["flow_loss"].item())
+    if variant.startswith("imf"):
+        for k, i in (("imf_loss", 5), ("aux_v_loss", 6), ("imf_mse", 7), ("aux_v_mse", 8)):
+            assert abs(losses[i].item() - m[k].item()) <= 1e-5 * abs(m[k].item()), k
     for k, gr in zip(keys, gs):
         if gr is None or gr.abs().max().item() == 0:
             assert grads[k].abs().max().item() == 0, f"{variant}: grad {k} should be zero"
@@ -151,8 +162,27 @@ def test_policy_mean_matcher_trains(dev):
     torch.manual_seed(0)
     tr.train_step(batch)        # the matcher's own (t, r) draw
     assert tr.metrics()["loss"] == tr.metrics()["loss"]
+    # improved_mean through the policy: the reference's metric keys, finite gradients; the dispersive term stays unbuilt
     cfg2 = small_cfg("cnn", matcher="improved_mean")
     cfg2.policy.flow_net.name = "simple_mean_flow_net"
-    pol2 = make_policy(cfg2, seed=2).to(dev)
+    cfg2.policy.flow_matcher.num_sampling_steps = 1
+    pol2 = make_policy(cfg2, seed=2)
+    with torch.no_grad():
+        for k, p in pol2.named_parameters():
+            if "output_layer" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(3)))
+    pol2 = pol2.to(dev)
+    pol2.train()
+    loss2, met2 = pol2.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev))
+    sd2 = {k: v.double() for k, v in hot_sd(pol2).items()}
+    ref2, m2 = O.compute_loss_meanflow(sd2, feats.double(), acts.double(), t.double(), r.double(), 1, use_imf=True)
+    assert set(met2) == set(m2), (sorted(met2), sorted(m2))
+    assert abs(loss2.item() - ref2.item()) <= 1e-5 * abs(ref2.item()) and abs(met2["aux_v_mse"] - m2["aux_v_mse"].item()) <= 1e-5 * abs(m2["aux_v_mse"].item())
+    loss2.backward()
+    assert pol2.flow_net.v_output_layer.weight.grad.abs().max().item() > 0
+    cfg3 = small_cfg("cnn", matcher="mean")
+    cfg3.policy.flow_net.name = "simple_mean_flow_net"
+    cfg3.policy.flow_matcher.dispersive_loss_weight = 0.5
+    pol3 = make_policy(cfg3, seed=2).to(dev)
     with pytest.raises(NotImplementedError):
-        pol2.compute_loss(nb)
+        pol3.compute_loss(nb)

@@ -181,15 +181,16 @@ def test_meanflow_training_losses_and_gradients_match_reference_autograd(golden_
     v = load(os.path.join(golden_dir, "meanflow_train.safetensors"))
     sd = {k[len("mf/sd/"):]: x for k, x in v.items() if k.startswith("mf/sd/")}
     obs, actions, t, r = (v["mf/" + k] for k in ("obs_features", "actions", "t", "r"))
-    for K in (1, 3):
+    for K, use_imf in ((1, False), (3, False), (1, True), (2, True)):
+        tag = f"mf/{'imf_' if use_imf else ''}K{K}"
         sdg = {k: x.clone().requires_grad_(True) for k, x in sd.items()}
-        loss, m = O.compute_loss_meanflow(sdg, obs, actions, t, r, K)
+        loss, m = O.compute_loss_meanflow(sdg, obs, actions, t, r, K, use_imf=use_imf)
         for k in m:
-            close(m[k].detach().reshape(1), v[f"mf/K{K}/loss/{k}"], 3e-6)
+            close(m[k].detach().reshape(1), v[f"{tag}/loss/{k}"], 3e-6)
         keys = list(sdg)
         gs = torch.autograd.grad(loss, [sdg[k] for k in keys], allow_unused=True)
         for k, g in zip(keys, gs):
-            ref = v[f"mf/K{K}/grad/{k}"]
+            ref = v[f"{tag}/grad/{k}"]
             if g is None:
                 assert ref.abs().max().item() == 0.0, k        # the v head takes no part without use_imf
             else:

@@ -49,8 +49,9 @@ def main():
     for k, v in sd.items():
         out[f"mf/sd/{k}"] = v
     out["mf/obs_features"], out["mf/actions"], out["mf/t"], out["mf/r"] = obs_features, actions, t, r
-    for K in (1, 3):
-        FM = G.fmm.MeanFlowConditionalFlowMatcher(num_sampling_steps=K)
+    for K, use_imf in ((1, False), (3, False), (1, True), (2, True)):
+        tag = f"mf/{'imf_' if use_imf else ''}K{K}"
+        FM = (G.fmm.ImprovedMeanFlowConditionalFlowMatcher if use_imf else G.fmm.MeanFlowConditionalFlowMatcher)(num_sampling_steps=K)
         FM.sample_t_r = lambda batch_size, device: (t.clone(), r.clone())
         for mod in (net, enc, dec, obs):
             mod.zero_grad(set_to_none=True)
@@ -66,16 +67,21 @@ def main():
         r2 = F.l1_loss(dec(act_lat), actions)
         loss = loss + 1.0 * cons + 0.5 * r1 + 0.5 * r2
         loss.backward()
-        ref = dict(meanflow_loss=flow_loss, flow_loss=flow_loss, consistency_loss=cons, flow_action_recon_loss=r1, enc_action_recon_loss=r2,
-                   loss=loss)
-        assert abs(met["meanflow_loss"] - flow_loss.item()) < 1e-12
-        oloss, omet = O.compute_loss_meanflow(sd, obs_features, actions, t, r, K)
+        ref = dict(flow_loss=flow_loss, consistency_loss=cons, flow_action_recon_loss=r1, enc_action_recon_loss=r2, loss=loss)
+        if not use_imf:
+            ref["meanflow_loss"] = flow_loss
+            assert abs(met["meanflow_loss"] - flow_loss.item()) < 1e-12
+        oloss, omet = O.compute_loss_meanflow(sd, obs_features, actions, t, r, K, use_imf=use_imf)
         for k, v in ref.items():
-            out[f"mf/K{K}/loss/{k}"] = v.detach().reshape(1).clone()
-            G.eq(omet[k].reshape(1), v.detach().reshape(1), f"meanflow K={K} {k}")
+            out[f"{tag}/loss/{k}"] = v.detach().reshape(1).clone()
+            G.eq(omet[k].reshape(1), v.detach().reshape(1), f"meanflow {tag} {k}")
+        if use_imf:     # the matcher reports these four as python floats (.item())
+            for k in ("imf_loss", "aux_v_loss", "imf_mse", "aux_v_mse"):
+                out[f"{tag}/loss/{k}"] = torch.tensor([met[k]], dtype=torch.float32)
+                assert abs(omet[k].item() - met[k]) <= 1e-12 + 1e-7 * abs(met[k]), (k, omet[k].item(), met[k])
         for prefix, mod in (("flow_net.", net), ("action_encoder.", enc), ("action_decoder.", dec), ("obs_encoder.", obs)):
             for n, p in mod.named_parameters():
-                out[f"mf/K{K}/grad/{prefix}{n}"] = p.grad.clone() if p.grad is not None else torch.zeros_like(p)
+                out[f"{tag}/grad/{prefix}{n}"] = p.grad.clone() if p.grad is not None else torch.zeros_like(p)
     path = os.path.join(REPO, "tests", "golden", "meanflow_train.safetensors")
     save_file({k: v.contiguous() for k, v in out.items()}, path)
     print("meanflow_train:", len(out), "tensors ->", path)

@@ -122,6 +122,7 @@ class MeanFlowLossConfig(C.Structure):
         ("num_steps", C.c_int32), ("recon_l1", C.c_int32), ("decode_flow_latents", C.c_int32),
         ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
         ("adaptive_loss_gamma", C.c_float), ("adaptive_loss_c", C.c_float),
+        ("use_imf", C.c_int32), ("norm_p", C.c_float), ("norm_eps", C.c_float), ("aux_v_loss_weight", C.c_float),
     ]
 
 
@@ -139,6 +140,9 @@ FM_CONDITIONAL, FM_TARGET, FM_SCHRODINGER = 0, 1, 2
 LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "enc_contrastive_loss",
               "flow_contrastive_loss", "action_kl_loss")
 LOSS_COUNT = 8
+MF_LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "imf_loss", "aux_v_loss",
+                 "imf_mse", "aux_v_mse")
+MF_LOSS_COUNT = 12
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
 SIGNATURES = {

@@ -916,8 +916,9 @@ namespace {
 
 constexpr int MFT = 256;
 // tv/hv rows: [0,B) = (t, t - r); B + k = (1 - k/K, (1 - k/K) - (1 - (k+1)/K)) in double as the reference's python floats; ones[b] = 1
+// with imf: B more rows (t, h = t - t = 0) for the no-grad evaluation that supplies the tangent (:138-140)
 __global__ __launch_bounds__(MFT) void mf_prep_kernel(const float* __restrict__ t, const float* __restrict__ r, float* __restrict__ tv,
-                                                     float* __restrict__ hv, float* __restrict__ ones, int B, int K) {
+                                                     float* __restrict__ hv, float* __restrict__ ones, int B, int K, int imf) {
     const int i = blockIdx.x * MFT + threadIdx.x;
     if (i < B) { tv[i] = t[i]; hv[i] = t[i] - r[i]; ones[i] = 1.0f; }
     else if (i < B + K) {
@@ -925,6 +926,48 @@ __global__ __launch_bounds__(MFT) void mf_prep_kernel(const float* __restrict__ 
         const double ts = 1.0 - (double)k / (double)K, rs = 1.0 - (double)(k + 1) / (double)K;
         tv[i] = (float)ts;
         hv[i] = (float)(ts - rs);
+    } else if (imf && i < 2 * B + K) {
+        const float tb = t[i - B - K];
+        tv[i] = tb;
+        hv[i] = tb - tb;
+    }
+}
+// improved MeanFlow (:153-155, 21-24), one wave per row: e1 = (u + h*dudt) - v, e2 = vpred - v; ps = sum_d e^2;
+// w = (ps + eps)^p; rows = ps / w; mse rows = ps / D
+__global__ __launch_bounds__(MFT) void imf_loss_rows_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ dudt,
+                                                           const float* __restrict__ vpred, const float* __restrict__ hv, int B, int D, float p,
+                                                           float eps, float* __restrict__ r1, float* __restrict__ r2, float* __restrict__ m1,
+                                                           float* __restrict__ m2, float* __restrict__ w1, float* __restrict__ w2) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float h = hv[row];
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = lane; k < D; k += 64) {
+        const int64_t i = (int64_t)row * D + k;
+        const float e1 = (u[i] + h * dudt[i]) - v[i], e2 = vpred[i] - v[i];
+        s1 += e1 * e1;
+        s2 += e2 * e2;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        const float a1 = powf(s1 + eps, p), a2 = powf(s2 + eps, p);
+        r1[row] = s1 / a1; r2[row] = s2 / a2;
+        m1[row] = s1 / (float)D; m2[row] = s2 / (float)D;
+        w1[row] = a1; w2[row] = a2;
+    }
+}
+// du = (1/B) * 2*e1 / w1_b ; dvp = aux_w * (1/B) * 2*e2 / w2_b
+__global__ __launch_bounds__(MFT) void imf_loss_bwd_kernel(const float* __restrict__ u, const float* __restrict__ v, const float* __restrict__ dudt,
+                                                          const float* __restrict__ vpred, const float* __restrict__ hv, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, int B, int D, float aux_w, float* __restrict__ du,
+                                                          float* __restrict__ dvp) {
+    const int64_t n = (int64_t)B * D, stride = (int64_t)gridDim.x * MFT;
+    for (int64_t i = (int64_t)blockIdx.x * MFT + threadIdx.x; i < n; i += stride) {
+        const int row = (int)(i / D);
+        const float e1 = (u[i] + hv[row] * dudt[i]) - v[i], e2 = vpred[i] - v[i];
+        du[i] = ((2.0f * e1) / w1[row]) / (float)B;
+        dvp[i] = aux_w * (((2.0f * e2) / w2[row]) / (float)B);
     }
 }
 // one wave per row: err = u - (v - h*dudt); delta = mean_d err^2; w = 1 / (delta + c)^p; rows[b] = w * delta, wrow[b] = w
@@ -985,6 +1028,7 @@ struct MfTrainWs {
     float *X0, *Xs, *Xc, *U1, *S;                                  // stacked evaluations
     float *xd0, *xd1, *xcd, *u1d, *sd, *dudt;                      // tangent pass (B rows)
     float *z0, *ZZ, *v, *u0, *rows, *wrow;
+    float *vpred, *vnet, *DV, *rows2, *wrow2, *mrow1, *mrow2;      // improved MeanFlow
     float *DU, *DX, *dz0, *dZZ, *dxa, *dxb, *dzt, *dtc, *dtmp, *dA1;
     StackWs dec, senc;
     CnnWs cnn;
@@ -999,7 +1043,8 @@ int max_colsum_n_mf(const vita_meanflow_policy_weights& w) {
 MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const vita_meanflow_loss_config& cfg, size_t B) {
     Carver c(ws);
     MfTrainWs s{};
-    const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0, T = B + K, E = 1 + K;
+    // improved MeanFlow: one more (forward-only) evaluation slot and B more conditioning rows
+    const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0, imf = cfg.use_imf ? 1 : 0, T = B + K + imf * B, E = 1 + K + imf;
     const size_t D = w.flow.D, H = w.flow.H, FF = w.flow.FF, L = w.flow.L;
     s.sk = c.take(kSplitkBytes / sizeof(float));
     s.consts = c.take(16);
@@ -1015,6 +1060,10 @@ MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const 
     s.S = c.take((L ? L : 1) * E * B * FF);
     s.xd0 = c.take(B * H); s.xd1 = c.take(B * H); s.xcd = c.take(B * H); s.u1d = c.take(B * FF); s.sd = c.take(B * FF); s.dudt = c.take(B * D);
     s.z0 = c.take(B * D); s.ZZ = c.take(2 * B * D); s.v = c.take(B * D); s.u0 = c.take(B * D); s.rows = c.take(B); s.wrow = c.take(B);
+    if (imf) {
+        s.vpred = c.take(B * D); s.vnet = c.take(B * D); s.DV = c.take(B * D);
+        s.rows2 = c.take(B); s.wrow2 = c.take(B); s.mrow1 = c.take(B); s.mrow2 = c.take(B);
+    }
     s.DU = c.take(E * B * D);
     s.DX = c.take((L + 1) * E * B * H);
     s.dz0 = c.take(B * D); s.dZZ = c.take(2 * B * D); s.dxa = c.take(B * D); s.dxb = c.take(B * D); s.dzt = c.take(B * D);
@@ -1078,10 +1127,15 @@ int mf_tangent_fwd(const MfCtx& c, const float* dz, const float* dtc) {
     return gemm_f32(lin(xd, H, w->u_w, H, nullptr, s.dudt, D, B, D, H, VITA_ACT_NONE), c.st);
 }
 // input-gradient chain of evaluation e from DU(e); leaves DX(l, e) for every l, dU1 in U1(l, e); dx = resid + DX(0,e) . W_in
-int mf_chain_bwd(const MfCtx& c, int e, float* dx, int64_t ld_dx, const float* resid, int64_t ld_resid) {
+int mf_chain_bwd(const MfCtx& c, int e, float* dx, int64_t ld_dx, const float* resid, int64_t ld_resid, const float* dv = nullptr) {
     const vita_meanflow_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, B = c.B, L = w->L;
     VITA_TRY(gemm_f32(dgrad(c.DU(e), D, w->u_w, H, c.DX(L, e), H, B, H, D), c.st));
+    if (dv) {   // the v head's gradient joins d x_L (improved MeanFlow's auxiliary loss)
+        vita_linear_args a = dgrad(dv, D, w->v_w, H, c.DX(L, e), H, B, H, D);
+        a.resid = c.DX(L, e); a.ld_resid = H;
+        VITA_TRY(gemm_f32(a, c.st));
+    }
     for (int l = L - 1; l >= 0; --l) {
         vita_linear_args a = dgrad(c.DX(l + 1, e), H, w->fc2_w[l], FF, c.U1(l, e), FF, B, FF, H);        // dU1 = (dY . W2) * silu'(U1), in place
         a.act = VITA_ACT_SILU; a.act_grad_z = c.U1(l, e); a.ld_act_grad_z = FF;
@@ -1144,7 +1198,12 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     const vita_meanflow_weights* fw = &w->flow;
     const int D = fw->D, H = fw->H, FF = fw->FF, L = fw->L, OUT = w->dec.OUT;
     const bool do_sample = cfg->decode_flow_latents != 0;
-    const int K = do_sample ? cfg->num_steps : 0, T = B + K, E = 1 + K;
+    const bool imf = cfg->use_imf != 0;
+    VITA_REQUIRE(!imf || (fw->v_w && fw->v_b && (!grads || (grads->flow.v_w && grads->flow.v_b))), "%s: improved MeanFlow needs the v head", who);
+    VITA_REQUIRE(!imf || (cfg->norm_eps > 0.f && cfg->aux_v_loss_weight >= 0.f), "%s: bad norm_eps / aux_v_loss_weight", who);
+    // conditioning rows: [B per-row (t, h) | K sampler steps | imf: B rows (t, 0)]; evaluation slots: 0 = JVP primal, 1..K sampler,
+    // imf: slot 1 + K = the forward-only evaluation that supplies the tangent.  Tc = rows that carry gradient, Eg likewise.
+    const int K = do_sample ? cfg->num_steps : 0, Tc = B + K, T = Tc + (imf ? B : 0), Eg = 1 + K, E = Eg + (imf ? 1 : 0);
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
     const bool dec_enc = cfg->enc_recon_weight > 0.f;
@@ -1154,7 +1213,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     SplitkScope skscope(s.sk, kSplitkBytes);
     const float seeds[4] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight};
     VITA_TRY(launch_set_scalars(s.consts, seeds, 4, st));
-    VITA_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * VITA_LOSS_COUNT, st));
+    VITA_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * VITA_MF_LOSS_COUNT, st));
 
     // ---- forward ------------------------------------------------------------------------------
     VITA_TRY(gemm_f32(lin(obs_features, ldobs, w->obs_w, w->O, w->obs_b, s.z0, D, B, D, w->O, VITA_ACT_NONE), st));
@@ -1163,7 +1222,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         es.senc = s.senc; es.cnn = s.cnn;
         VITA_TRY(encoder_fwd(w->enc, es, actions, z1, D, B, st));
     }
-    hipLaunchKernelGGL(mf_prep_kernel, dim3((T + MFT - 1) / MFT), dim3(MFT), 0, st, t, r, s.tv, s.hv, s.ones, B, K);
+    hipLaunchKernelGGL(mf_prep_kernel, dim3((T + MFT - 1) / MFT), dim3(MFT), 0, st, t, r, s.tv, s.hv, s.ones, B, K, imf ? 1 : 0);
     VITA_CHECK_HIP(hipGetLastError());
     // time conditioning for the T rows, keeping the pre-activations              simple_mean_flow_net.py:64-67
     {
@@ -1193,11 +1252,29 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     VITA_TRY(vita_cfm_interpolate_f32(z1, s.z0, t, nullptr, nullptr, mc.X0(0), s.v, B, D, st));
     VITA_TRY(mf_trunk_fwd(mc, 0, s.tc, H));
     VITA_TRY(gemm_f32(lin(mc.Xs(L, 0), H, fw->u_w, H, fw->u_b, s.u0, D, B, D, H, VITA_ACT_NONE), st));
-    VITA_TRY(mf_tangent_fwd(mc, s.v, s.dtc_tan));
-    const float pexp = 1.0f - cfg->adaptive_loss_gamma;
-    hipLaunchKernelGGL(mf_loss_rows_kernel, dim3((B + 3) / 4), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, B, D, pexp, cfg->adaptive_loss_c, s.rows, s.wrow);
-    hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.rows, B, losses + VITA_LOSS_FLOW);
-    VITA_CHECK_HIP(hipGetLastError());
+    if (imf) {
+        // tangent = the v head at (z_t, t, r = t), no grad (:138-140): forward-only slot E - 1 with the (t, 0) conditioning rows
+        VITA_CHECK_HIP(hipMemcpyAsync(mc.X0(E - 1), mc.X0(0), (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
+        VITA_TRY(mf_trunk_fwd(mc, E - 1, s.tc + (size_t)Tc * H, H));
+        VITA_TRY(gemm_f32(lin(mc.Xs(L, E - 1), H, fw->v_w, H, fw->v_b, s.vnet, D, B, D, H, VITA_ACT_NONE), st));
+        VITA_TRY(gemm_f32(lin(mc.Xs(L, 0), H, fw->v_w, H, fw->v_b, s.vpred, D, B, D, H, VITA_ACT_NONE), st));
+        VITA_TRY(mf_tangent_fwd(mc, s.vnet, s.dtc_tan));
+        hipLaunchKernelGGL(imf_loss_rows_kernel, dim3((B + 3) / 4), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.vpred, s.hv, B, D, cfg->norm_p, cfg->norm_eps,
+                           s.rows, s.rows2, s.mrow1, s.mrow2, s.wrow, s.wrow2);
+        hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.rows, B, losses + VITA_MF_LOSS_IMF);
+        hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.rows2, B, losses + VITA_MF_LOSS_AUX_V);
+        hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.mrow1, B, losses + VITA_MF_LOSS_IMF_MSE);
+        hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.mrow2, B, losses + VITA_MF_LOSS_AUX_V_MSE);
+        VITA_CHECK_HIP(hipGetLastError());
+        const float fsum[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 1.0f, cfg->aux_v_loss_weight};
+        VITA_TRY(launch_weighted_sum(losses, fsum, 7, losses + VITA_MF_LOSS_FLOW, st));     // :157
+    } else {
+        VITA_TRY(mf_tangent_fwd(mc, s.v, s.dtc_tan));
+        const float pexp = 1.0f - cfg->adaptive_loss_gamma;
+        hipLaunchKernelGGL(mf_loss_rows_kernel, dim3((B + 3) / 4), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, B, D, pexp, cfg->adaptive_loss_c, s.rows, s.wrow);
+        hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.rows, B, losses + VITA_MF_LOSS_FLOW);
+        VITA_CHECK_HIP(hipGetLastError());
+    }
     // MeanFlow sampler with grad                                                  mean_flow_matcher.py:201-233
     auto hstep = [&](int k) { return (float)((1.0 - (double)k / (double)K) - (1.0 - (double)(k + 1) / (double)K)); };
     if (do_sample) {
@@ -1257,9 +1334,13 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     float* dz1 = s.dZZ + (size_t)B * D;
     if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
     // MeanFlow loss -> DU(0); primal chain of evaluation 0 -> d z_t
-    hipLaunchKernelGGL(mf_loss_bwd_kernel, dim3(mfgrid((int64_t)B * D)), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, s.wrow, B, D, mc.DU(0));
+    if (imf)
+        hipLaunchKernelGGL(imf_loss_bwd_kernel, dim3(mfgrid((int64_t)B * D)), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.vpred, s.hv, s.wrow, s.wrow2, B, D,
+                           cfg->aux_v_loss_weight, mc.DU(0), s.DV);
+    else
+        hipLaunchKernelGGL(mf_loss_bwd_kernel, dim3(mfgrid((int64_t)B * D)), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, s.wrow, B, D, mc.DU(0));
     VITA_CHECK_HIP(hipGetLastError());
-    VITA_TRY(mf_chain_bwd(mc, 0, s.dzt, D, nullptr, 0));
+    VITA_TRY(mf_chain_bwd(mc, 0, s.dzt, D, nullptr, 0, imf ? s.DV : nullptr));
     // conditioning gradients, eval 0: per row, dtc[b] = DX(0,0)[b] - DX(L,0)[b]  (sum over layers of d x_cond telescopes)
     hipLaunchKernelGGL(mf_sub_kernel, dim3(mfgrid((int64_t)B * H)), dim3(MFT), 0, st, mc.DX(0, 0), mc.DX(L, 0), s.dtc, (int64_t)B * H);
     VITA_CHECK_HIP(hipGetLastError());
@@ -1282,7 +1363,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dzt, nullptr, t, nullptr, nullptr, dz1, s.dz0, B, D, 1, st));
     // weight gradients over the stacked E*B rows
     {
-        const int R = E * B;
+        const int R = Eg * B;      // the forward-only slot of improved MeanFlow carries no gradient
         VITA_TRY(gemm_f32(wgrad(s.DU, D, mc.Xs(L, 0), H, mut(gf.u_w), H, R, H, D), st));
         VITA_TRY(vita_colsum_f32(s.DU, D, R, D, s.cs_part, mut(gf.u_b), 0, st));
         for (int l = 0; l < L; ++l) {
@@ -1293,8 +1374,13 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         }
         VITA_TRY(gemm_f32(wgrad(mc.DX(0, 0), H, s.X0, D, mut(gf.in_w), D, R, D, H), st));
         VITA_TRY(vita_colsum_f32(mc.DX(0, 0), H, R, H, s.cs_part, mut(gf.in_b), 0, st));
-        if (gf.v_w) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_w), 0, (size_t)D * H * 4, st));    // the v head takes no part (use_imf = False)
-        if (gf.v_b) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_b), 0, (size_t)D * 4, st));
+        if (imf) {      // the v head is used by evaluation 0 only
+            VITA_TRY(gemm_f32(wgrad(s.DV, D, mc.Xs(L, 0), H, mut(gf.v_w), H, B, H, D), st));
+            VITA_TRY(vita_colsum_f32(s.DV, D, B, D, s.cs_part, mut(gf.v_b), 0, st));
+        } else {        // the v head takes no part (use_imf = False)
+            if (gf.v_w) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_w), 0, (size_t)D * H * 4, st));
+            if (gf.v_b) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_b), 0, (size_t)D * 4, st));
+        }
     }
     // conditioning path: tc = t2(silu(t1 t)) + h2(silu(h1 h)) over the T rows
     {
@@ -1302,13 +1388,13 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         const Br brs[2] = {{s.tv, s.At, s.St, fw->t1_w, fw->t2_w, gf.t1_w, gf.t1_b, gf.t2_w, gf.t2_b},
                            {s.hv, s.Ah, s.Sh, fw->h1_w, fw->h2_w, gf.h1_w, gf.h1_b, gf.h2_w, gf.h2_b}};
         for (const Br& b : brs) {
-            VITA_TRY(gemm_f32(wgrad(s.dtc, H, b.Sx, H, mut(b.gw2), H, T, H, H), st));
-            VITA_TRY(vita_colsum_f32(s.dtc, H, T, H, s.cs_part, mut(b.gb2), 0, st));
-            vita_linear_args a = dgrad(s.dtc, H, b.w2, H, s.dA1, H, T, H, H);
+            VITA_TRY(gemm_f32(wgrad(s.dtc, H, b.Sx, H, mut(b.gw2), H, Tc, H, H), st));
+            VITA_TRY(vita_colsum_f32(s.dtc, H, Tc, H, s.cs_part, mut(b.gb2), 0, st));
+            vita_linear_args a = dgrad(s.dtc, H, b.w2, H, s.dA1, H, Tc, H, H);
             a.act = VITA_ACT_SILU; a.act_grad_z = b.A; a.ld_act_grad_z = H;
             VITA_TRY(gemm_f32(a, st));
-            VITA_TRY(gemm_f32(wgrad(s.dA1, H, b.in, 1, mut(b.gw1), 1, T, 1, H), st));
-            VITA_TRY(vita_colsum_f32(s.dA1, H, T, H, s.cs_part, mut(b.gb1), 0, st));
+            VITA_TRY(gemm_f32(wgrad(s.dA1, H, b.in, 1, mut(b.gw1), 1, Tc, 1, H), st));
+            VITA_TRY(vita_colsum_f32(s.dA1, H, Tc, H, s.cs_part, mut(b.gb1), 0, st));
         }
     }
     // encoders

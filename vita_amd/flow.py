@@ -150,14 +150,14 @@ class _InferenceOnlyMatcher:
 
 class MeanFlowMatcher(_InferenceOnlyMatcher):
     """flow/mean_flow_matcher.py:42-233 — constructor arguments kept; `.sample` is ONE C-ABI call over a
-    `vita_amd.ops.MeanFlowNetHandle` (SimpleMeanFlowNet).  Training: the MeanFlow loss (use_imf = False, dispersive weight 0:
-    JVP target, adaptive L2 loss, :109-183) runs inside the policy's fused MeanFlow step (vita_compute_loss_meanflow_f32) with
-    the (t, r) draw of `sample_t_r` made here on the host as in the reference; improved MeanFlow (use_imf) and the dispersive
-    term are not built."""
+    `vita_amd.ops.MeanFlowNetHandle` (SimpleMeanFlowNet).  Training: the MeanFlow loss (JVP target + adaptive L2 loss, :164-183) and the
+    improved-MeanFlow loss (use_imf: no-grad v-head tangent, compound velocity, auxiliary v loss, :137-163) run inside the
+    policy's fused MeanFlow step (vita_compute_loss_meanflow_f32) with the (t, r) draw of `sample_t_r` made here on the host as
+    in the reference; the dispersive term (dispersive_loss_weight > 0) is not built."""
 
     @property
     def inference_only(self) -> bool:
-        return bool(self.use_imf) or float(self.dispersive_loss_weight) > 0.0
+        return float(self.dispersive_loss_weight) > 0.0
 
     def sample_t_r(self, batch_size, device):
         """mean_flow_matcher.py:87-107, statement for statement (torch's generators, as in the reference)."""
@@ -180,7 +180,7 @@ class MeanFlowMatcher(_InferenceOnlyMatcher):
 
     def compute_loss(self, model, target, start=None, **kwargs):
         raise NotImplementedError("MeanFlowMatcher.compute_loss on its own is not exposed: the MeanFlow loss runs inside "
-                                  "VitaPolicy.compute_loss (vita_compute_loss_meanflow_f32); improved MeanFlow / the dispersive term are not built")
+                                  "VitaPolicy.compute_loss (vita_compute_loss_meanflow_f32); the dispersive term is not built")
 
     def sample(self, model: "ops.MeanFlowNetHandle", shape, device, num_steps=None, return_traces=False, start=None, **kwargs):
         """mean_flow_matcher.py:201-233."""

@@ -875,6 +875,8 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
         raise L.VitaHipError("compute_loss: this flow matcher adds noise to xt: pass fm_noise (B, D)")
     if losses is None:
         losses = torch.empty(L.LOSS_COUNT, dtype=torch.float32, device=dev)
+    elif losses.numel() < L.LOSS_COUNT:
+        raise L.VitaHipError(f"compute_loss: losses needs {L.LOSS_COUNT} floats")
     dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
     ev = None
     if grad_ready_events is not None:
@@ -921,20 +923,22 @@ class MeanFlowPolicyHandle:
 
 def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
                          enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, adaptive_loss_gamma: float = 0.5,
-                         adaptive_loss_c: float = 1e-3) -> "L.MeanFlowLossConfig":
+                         adaptive_loss_c: float = 1e-3, use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01,
+                         aux_v_loss_weight: float = 1.0) -> "L.MeanFlowLossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")
     c = L.MeanFlowLossConfig()
     c.num_steps, c.recon_l1, c.decode_flow_latents = num_steps, int(recon == "l1"), int(decode_flow_latents)
     c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
     c.adaptive_loss_gamma, c.adaptive_loss_c = adaptive_loss_gamma, adaptive_loss_c
+    c.use_imf, c.norm_p, c.norm_eps, c.aux_v_loss_weight = int(use_imf), norm_p, norm_eps, aux_v_loss_weight
     return c
 
 
 def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, r: Tensor, *,
                           grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None) -> Tensor:
     """VitaPolicy.compute_loss with the MeanFlow matcher (+ backward when `grads` is given): vita_compute_loss_meanflow_f32.
-    Returns losses (8,) indexed as _lib.LOSS_NAMES with index 1 = meanflow_loss.  No host sync."""
+    Returns losses (12,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss).  No host sync."""
     lib = L.load()
     obs_features = _rows(obs_features, "compute_loss_meanflow: obs_features")
     actions = _f32(actions, "compute_loss_meanflow: actions").contiguous()
@@ -946,7 +950,9 @@ def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, a
                              f"r {tuple(r.shape)} do not match O={pw.O}, T={pw.T}, A={pw.A}")
     dev = obs_features.device
     if losses is None:
-        losses = torch.empty(L.LOSS_COUNT, dtype=torch.float32, device=dev)
+        losses = torch.empty(L.MF_LOSS_COUNT, dtype=torch.float32, device=dev)
+    elif losses.numel() < L.MF_LOSS_COUNT:
+        raise L.VitaHipError(f"compute_loss_meanflow: losses needs {L.MF_LOSS_COUNT} floats")
     nbytes = lib.vita_compute_loss_meanflow_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
     ws = workspace(dev, nbytes)
     L.check(lib.vita_compute_loss_meanflow_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),

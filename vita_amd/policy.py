@@ -330,7 +330,9 @@ class VitaPolicy(nn.Module):
                                                     consistency_weight=float(pol.vita.consistency_weight),
                                                     enc_recon_weight=float(self.enc_action_recon_weight),
                                                     flow_recon_weight=float(self.flow_action_recon_weight),
-                                                    adaptive_loss_gamma=float(self.FM.adaptive_loss_gamma))
+                                                    adaptive_loss_gamma=float(self.FM.adaptive_loss_gamma), use_imf=bool(self.FM.use_imf),
+                                                    norm_p=float(self.FM.norm_p), norm_eps=float(self.FM.norm_eps),
+                                                    aux_v_loss_weight=float(self.FM.aux_v_loss_weight))
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -570,7 +572,10 @@ class VitaPolicy(nn.Module):
             losses = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r)
             loss = losses[0]
         vals = losses.detach().cpu().tolist()
-        metrics = {"meanflow_loss": vals[1], "loss": vals[1], "flow_loss": vals[1]}
+        if self.FM.use_imf:     # mean_flow_matcher.py:158-163, 197
+            metrics = {"imf_loss": vals[5], "aux_v_loss": vals[6], "imf_mse": vals[7], "aux_v_mse": vals[8], "loss": vals[1], "flow_loss": vals[1]}
+        else:
+            metrics = {"meanflow_loss": vals[1], "loss": vals[1], "flow_loss": vals[1]}
         cfgv = self.config.policy.vita
         if cfgv.decode_flow_latents:
             if cfgv.consistency_weight > 0:

@@ -49,7 +49,7 @@ class PolicyTrainer:
                 e.record(torch.cuda.current_stream(self.device))
         self.num_training_steps = num_training_steps or config.train.steps
         self.step_counter = 0
-        self.losses = torch.zeros(L.LOSS_COUNT, dtype=torch.float32, device=self.device)
+        self.losses = torch.zeros(max(L.LOSS_COUNT, L.MF_LOSS_COUNT), dtype=torch.float32, device=self.device)
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=self.device)
         self.update_s = 0.0
         if self.world > 1:
@@ -96,7 +96,8 @@ class PolicyTrainer:
         """One device->host copy: the metric keys of vita_policy.py:132-186 plus grad_norm / lr (policy_trainer.py:97-99).
         Under data parallelism the loss values are this rank's shard means."""
         vals = self.losses.cpu().tolist()
-        out = {k: vals[i] for i, k in enumerate(L.LOSS_NAMES)}
+        names = L.MF_LOSS_NAMES if getattr(self.network, "mean_flow", False) else L.LOSS_NAMES
+        out = {k: vals[i] for i, k in enumerate(names)}
         out["grad_norm"] = float(self.gnorm_sq.sqrt().item()) / self.world
         out["lr"] = self.current_lr()
         out["update_s"] = self.update_s
