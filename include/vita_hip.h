@@ -464,7 +464,7 @@ int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, in
  *   losses: device float[VITA_MF_LOSS_COUNT], indexed by VITA_MF_LOSS_*.
  *   grads: NULL = forward only; else every gradient buffer is overwritten (without use_imf the v head's with zeros: it takes no part).
  * use_imf = 1 is improved MeanFlow (flow_matcher.name = "improved_mean", :137-163).
- * Not built here: the dispersive term, the variational encoder, freeze flags, contrastive terms. */
+ * Not built here: the variational encoder, freeze flags, contrastive terms. */
 typedef struct vita_meanflow_policy_weights {
     int32_t O;
     const float *obs_w, *obs_b;
@@ -481,11 +481,15 @@ typedef struct vita_meanflow_loss_config {
                                     compound = u + h*stopgrad(dudt) against v, plus the auxiliary v-head loss */
     float norm_p, norm_eps;      /* adaptive_imf_loss (:21-24): per-sample sum of squares / stopgrad((that + norm_eps)^norm_p) */
     float aux_v_loss_weight;
+    float dispersive_loss_weight; /* > 0: + weight * sum over the hidden layers' outputs of dispersive_loss (:27-39, 185-195): */
+    float dispersive_loss_tau;    /*   log(mean(exp(-cdist(z, z)^2 / (max(cdist^2).detach() + 1e-8) / tau))) over the batch */
 } vita_meanflow_loss_config;
 /* losses of the MeanFlow step: device float[VITA_MF_LOSS_COUNT] */
 enum { VITA_MF_LOSS_TOTAL = 0, VITA_MF_LOSS_FLOW = 1 /* meanflow_loss, or imf_loss + aux_v_loss_weight * aux_v_loss */,
        VITA_MF_LOSS_CONSISTENCY = 2, VITA_MF_LOSS_FLOW_RECON = 3, VITA_MF_LOSS_ENC_RECON = 4, VITA_MF_LOSS_IMF = 5, VITA_MF_LOSS_AUX_V = 6,
-       VITA_MF_LOSS_IMF_MSE = 7, VITA_MF_LOSS_AUX_V_MSE = 8, VITA_MF_LOSS_COUNT = 12 };
+       VITA_MF_LOSS_IMF_MSE = 7, VITA_MF_LOSS_AUX_V_MSE = 8, VITA_MF_LOSS_DISPERSIVE = 9 /* unweighted sum over layers */,
+       VITA_MF_LOSS_FLOW_BASE = 10 /* the matcher's loss before + weight * dispersive (its 'meanflow_loss' metric); written only with the dispersive term */,
+       VITA_MF_LOSS_COUNT = 12 };
 size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_weights* w, const vita_meanflow_loss_config* cfg, int32_t B);
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,

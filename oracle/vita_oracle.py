@@ -359,6 +359,27 @@ def mean_flow_sample(sd: SD, start: Tensor, num_steps: int = 1, prefix: str = "f
     return x
 
 
+def dispersive_loss(z: Tensor, tau: float = 1.0):
+    """dispersive_loss, mean_flow_matcher.py:27-39."""
+    if z.shape[0] <= 1:
+        return 0.0
+    dist = torch.cdist(z, z, p=2) ** 2
+    dist = dist / (torch.max(dist).detach() + 1e-8)
+    return torch.log(torch.mean(torch.exp(-dist / tau)))
+
+
+def mean_flow_dispersive_total(sd: SD, start: Tensor, target: Tensor, t: Tensor, r: Tensor, tau: float = 1.0,
+                               prefix: str = "flow_net."):
+    """Sum of dispersive_loss over the hidden layers' outputs at (z_t, t, r), mean_flow_matcher.py:185-192."""
+    t_ = t.view(-1, *([1] * (start.dim() - 1)))
+    z_t = (1 - t_) * target + t_ * start
+    feats = mean_flow_net_forward(sd, z_t, t, t - r, prefix)[2]
+    total = 0.0
+    for f in feats:
+        total = total + dispersive_loss(f, tau)
+    return total
+
+
 def improved_mean_flow_loss(sd: SD, start: Tensor, target: Tensor, t: Tensor, r: Tensor, norm_p: float = 1.0, norm_eps: float = 0.01,
                             aux_v_loss_weight: float = 1.0, prefix: str = "flow_net."):
     """MeanFlowMatcher.compute_loss with use_imf = True, mean_flow_matcher.py:137-163 (adaptive_imf_loss :21-24).
@@ -428,7 +449,8 @@ def mean_flow_sample_grad(sd: SD, start: Tensor, num_steps: int = 1, prefix: str
 def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, r: Tensor, num_steps: int = 1,
                           consistency_weight: float = 1.0, enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5,
                           recon_loss_type: str = "l1", decode_flow_latents: bool = True, adaptive_loss_gamma: float = 0.5,
-                          use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01, aux_v_loss_weight: float = 1.0):
+                          use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01, aux_v_loss_weight: float = 1.0,
+                          dispersive_loss_weight: float = 0.0, dispersive_loss_tau: float = 1.0):
     """VitaPolicy.compute_loss (vita_policy.py:112-189) with flow_matcher.name = 'mean' over SimpleMeanFlowNet: defaults
     otherwise (plain autoencoder, nothing frozen, no contrastive terms).  Returns (loss, metrics of 0-dim tensors)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
@@ -442,6 +464,10 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
     else:
         flow_loss = mean_flow_loss(sd, obs_latents, action_latents, t, r, adaptive_loss_gamma)    # :126-130
         m["meanflow_loss"] = flow_loss
+    if dispersive_loss_weight > 0:                                                                 # mean_flow_matcher.py:188-195
+        dis = mean_flow_dispersive_total(sd, obs_latents, action_latents, t, r, dispersive_loss_tau)
+        m["dispersive_loss"] = dis
+        flow_loss = flow_loss + dispersive_loss_weight * dis
     loss = flow_loss
     m["flow_loss"] = flow_loss
     if decode_flow_latents:                                                                        # :153-178

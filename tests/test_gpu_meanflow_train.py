@@ -57,14 +57,22 @@ IMF_KEYS = {"loss": 0, "flow_loss": 1, "consistency_loss": 2, "flow_action_recon
             "aux_v_loss": 6, "imf_mse": 7, "aux_v_mse": 8}
 
 
-@pytest.mark.parametrize("K,use_imf", [(1, False), (3, False), (1, True), (2, True)])
-def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf):
-    """mean (use_imf False) and improved_mean (use_imf True, mean_flow_matcher.py:137-163) against the reference's autograd."""
-    tag = f"mf/{'imf_' if use_imf else ''}K{K}"
+@pytest.mark.parametrize("K,use_imf,dw,tau", [(1, False, 0.0, 1.0), (3, False, 0.0, 1.0), (1, True, 0.0, 1.0), (2, True, 0.0, 1.0),
+                                              (1, False, 0.5, 1.0), (2, True, 0.25, 0.7)])
+def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf, dw, tau):
+    """mean (use_imf False) and improved_mean (use_imf True, mean_flow_matcher.py:137-163), without and with the dispersive
+    term (:185-195), against the reference's autograd."""
+    tag = f"mf/{'imf_' if use_imf else ''}{'disp_' if dw > 0 else ''}K{K}"
     sd = {k[len("mf/sd/"):]: v for k, v in gold.items() if k.startswith("mf/sd/")}
     obs, actions, t, r = (gold["mf/" + k] for k in ("obs_features", "actions", "t", "r"))
-    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, use_imf=use_imf))
-    for k, i in (IMF_KEYS if use_imf else KEYS).items():
+    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, use_imf=use_imf, dispersive_loss_weight=dw,
+                                                                                  dispersive_loss_tau=tau))
+    keys = dict(IMF_KEYS if use_imf else KEYS)
+    if dw > 0:
+        keys["dispersive_loss"] = 9
+        if not use_imf:
+            keys["meanflow_loss"] = 10
+    for k, i in keys.items():
         ref = gold[f"{tag}/loss/{k}"].item()
         assert abs(losses[i].item() - ref) <= 1e-5 * abs(ref), f"{tag} {k}: {losses[i].item()} vs {ref}"
     for k in sd:
@@ -76,7 +84,8 @@ def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf):
             assert nerr(grads[k], ref) <= 2e-5, f"K={K} grad {k}: {nerr(grads[k], ref):g}"
 
 
-@pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma", "imf_default_dims_b64", "imf_norm"])
+@pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma", "imf_default_dims_b64", "imf_norm",
+                                     "disp_default_dims_b64", "imf_disp"])
 def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     g = torch.Generator().manual_seed(31)
     kw, ck = {}, {}
@@ -84,7 +93,9 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
         kw.update(use_imf=True); ck.update(use_imf=True)
     if variant == "imf_norm":
         kw.update(norm_p=0.7, norm_eps=0.05, aux_v_loss_weight=0.3); ck.update(norm_p=0.7, norm_eps=0.05, aux_v_loss_weight=0.3)
-    if variant in ("default_dims_b64", "imf_default_dims_b64"):
+    if "disp" in variant:
+        kw.update(dispersive_loss_weight=0.5, dispersive_loss_tau=0.8); ck.update(dispersive_loss_weight=0.5, dispersive_loss_tau=0.8)
+    if variant in ("default_dims_b64", "imf_default_dims_b64", "disp_default_dims_b64"):
         A, T, B, D, H, Lh, O_, enc, aeh, ael = 21, 16, 64, 512, 512, 4, 533, "cnn", 512, 4
     else:
         A, T, B, D, H, Lh, O_, enc, aeh, ael = 7, 16, 19, 64, 64, 3, 40, ("simple" if variant == "l2_simple_encoder" else "cnn"), 48, (2 if variant == "l2_simple_encoder" else 4)
@@ -111,6 +122,8 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, **ck))
     assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item()), (losses[0].item(), loss.item())
     assert abs(losses[1].item() - m["flow_loss"].item()) <= 1e-5 * abs(m["flow_loss"].item())
+    if "disp" in variant:
+        assert abs(losses[9].item() - m["dispersive_loss"].item()) <= 1e-5 * abs(m["dispersive_loss"].item())
     if variant.startswith("imf"):
         for k, i in (("imf_loss", 5), ("aux_v_loss", 6), ("imf_mse", 7), ("aux_v_mse", 8)):
             assert abs(losses[i].item() - m[k].item()) <= 1e-5 * abs(m[k].item()), k
@@ -162,7 +175,7 @@ def test_policy_mean_matcher_trains(dev):
     torch.manual_seed(0)
     tr.train_step(batch)        # the matcher's own (t, r) draw
     assert tr.metrics()["loss"] == tr.metrics()["loss"]
-    # improved_mean through the policy: the reference's metric keys, finite gradients; the dispersive term stays unbuilt
+    # improved_mean through the policy: the reference's metric keys, finite gradients
     cfg2 = small_cfg("cnn", matcher="improved_mean")
     cfg2.policy.flow_net.name = "simple_mean_flow_net"
     cfg2.policy.flow_matcher.num_sampling_steps = 1
@@ -183,6 +196,16 @@ def test_policy_mean_matcher_trains(dev):
     cfg3 = small_cfg("cnn", matcher="mean")
     cfg3.policy.flow_net.name = "simple_mean_flow_net"
     cfg3.policy.flow_matcher.dispersive_loss_weight = 0.5
-    pol3 = make_policy(cfg3, seed=2).to(dev)
-    with pytest.raises(NotImplementedError):
-        pol3.compute_loss(nb)
+    cfg3.policy.flow_matcher.num_sampling_steps = 1
+    pol3 = make_policy(cfg3, seed=2).to(dev)        # the dispersive term through the policy
+    pol3.train()
+    loss3, met3 = pol3.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev))
+    sd3 = {k: v.double() for k, v in hot_sd(pol3).items()}
+    ref3, m3 = O.compute_loss_meanflow(sd3, feats.double(), acts.double(), t.double(), r.double(), 1, dispersive_loss_weight=0.5)
+    assert set(met3) == set(m3), (sorted(met3), sorted(m3))
+    assert abs(loss3.item() - ref3.item()) <= 1e-5 * abs(ref3.item())
+    for k in m3:
+        if k == "loss":     # the policy's metrics keep the matcher's own 'loss' (= flow_loss), the oracle's is the total
+            continue
+        assert abs(met3[k] - m3[k].item()) <= 1e-5 * abs(m3[k].item()) + 1e-7, (k, met3[k], m3[k].item())
+    loss3.backward()

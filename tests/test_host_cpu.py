@@ -123,7 +123,7 @@ def test_flow_matcher_table():
     m = get_flow_matcher("mean", sigma=0.0, num_sampling_steps=1, flow_ratio=0.25)          # MeanFlow swallows **kwargs (:56)
     assert not m.inference_only and m.flow_ratio == 0.25 and not m.use_imf      # MeanFlow training is built (fused MeanFlow step)
     im = get_flow_matcher("improved_mean")
-    assert im.use_imf and not im.inference_only and get_flow_matcher("mean", dispersive_loss_weight=0.1).inference_only
+    assert im.use_imf and not im.inference_only and not get_flow_matcher("mean", dispersive_loss_weight=0.1).inference_only
     tt, rr = m.sample_t_r(64, "cpu")                                                          # mean_flow_matcher.py:87-107
     assert tt.shape == (64,) and bool((tt >= rr).all()) and int((tt == rr).sum()) >= 16 and float(tt.max()) < 1 and float(rr.min()) > 0
     with pytest.raises(NotImplementedError):

@@ -49,9 +49,12 @@ def main():
     for k, v in sd.items():
         out[f"mf/sd/{k}"] = v
     out["mf/obs_features"], out["mf/actions"], out["mf/t"], out["mf/r"] = obs_features, actions, t, r
-    for K, use_imf in ((1, False), (3, False), (1, True), (2, True)):
-        tag = f"mf/{'imf_' if use_imf else ''}K{K}"
-        FM = (G.fmm.ImprovedMeanFlowConditionalFlowMatcher if use_imf else G.fmm.MeanFlowConditionalFlowMatcher)(num_sampling_steps=K)
+    # (num_steps, use_imf, dispersive_loss_weight, dispersive_loss_tau)
+    for K, use_imf, dw, tau in ((1, False, 0.0, 1.0), (3, False, 0.0, 1.0), (1, True, 0.0, 1.0), (2, True, 0.0, 1.0),
+                                (1, False, 0.5, 1.0), (2, True, 0.25, 0.7)):
+        tag = f"mf/{'imf_' if use_imf else ''}{'disp_' if dw > 0 else ''}K{K}"
+        FM = (G.fmm.ImprovedMeanFlowConditionalFlowMatcher if use_imf else G.fmm.MeanFlowConditionalFlowMatcher)(
+            num_sampling_steps=K, dispersive_loss_weight=dw, dispersive_loss_tau=tau)
         FM.sample_t_r = lambda batch_size, device: (t.clone(), r.clone())
         for mod in (net, enc, dec, obs):
             mod.zero_grad(set_to_none=True)
@@ -68,10 +71,17 @@ def main():
         loss = loss + 1.0 * cons + 0.5 * r1 + 0.5 * r2
         loss.backward()
         ref = dict(flow_loss=flow_loss, consistency_loss=cons, flow_action_recon_loss=r1, enc_action_recon_loss=r2, loss=loss)
-        if not use_imf:
+        if not use_imf and dw == 0:
             ref["meanflow_loss"] = flow_loss
             assert abs(met["meanflow_loss"] - flow_loss.item()) < 1e-12
-        oloss, omet = O.compute_loss_meanflow(sd, obs_features, actions, t, r, K, use_imf=use_imf)
+        oloss, omet = O.compute_loss_meanflow(sd, obs_features, actions, t, r, K, use_imf=use_imf, dispersive_loss_weight=dw,
+                                              dispersive_loss_tau=tau)
+        if dw > 0:
+            out[f"{tag}/loss/dispersive_loss"] = torch.tensor([met["dispersive_loss"]], dtype=torch.float32)
+            assert abs(omet["dispersive_loss"].item() - met["dispersive_loss"]) <= 1e-7 * abs(met["dispersive_loss"])
+            if not use_imf:
+                out[f"{tag}/loss/meanflow_loss"] = torch.tensor([met["meanflow_loss"]], dtype=torch.float32)
+                assert abs(omet["meanflow_loss"].item() - met["meanflow_loss"]) <= 1e-7 * abs(met["meanflow_loss"])
         for k, v in ref.items():
             out[f"{tag}/loss/{k}"] = v.detach().reshape(1).clone()
             G.eq(omet[k].reshape(1), v.detach().reshape(1), f"meanflow {tag} {k}")

@@ -123,6 +123,7 @@ class MeanFlowLossConfig(C.Structure):
         ("consistency_weight", C.c_float), ("enc_recon_weight", C.c_float), ("flow_recon_weight", C.c_float),
         ("adaptive_loss_gamma", C.c_float), ("adaptive_loss_c", C.c_float),
         ("use_imf", C.c_int32), ("norm_p", C.c_float), ("norm_eps", C.c_float), ("aux_v_loss_weight", C.c_float),
+        ("dispersive_loss_weight", C.c_float), ("dispersive_loss_tau", C.c_float),
     ]
 
 
@@ -141,7 +142,7 @@ LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss",
               "flow_contrastive_loss", "action_kl_loss")
 LOSS_COUNT = 8
 MF_LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "imf_loss", "aux_v_loss",
-                 "imf_mse", "aux_v_mse")
+                 "imf_mse", "aux_v_mse", "dispersive_loss")
 MF_LOSS_COUNT = 12
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against

@@ -1016,6 +1016,87 @@ __global__ __launch_bounds__(MFT) void mf_sub_kernel(const float* __restrict__ a
     const int64_t stride = (int64_t)gridDim.x * MFT;
     for (int64_t i = (int64_t)blockIdx.x * MFT + threadIdx.x; i < n; i += stride) out[i] = a[i] - b[i];
 }
+__global__ __launch_bounds__(MFT) void mf_sub_inplace_kernel(float* out, const float* __restrict__ b, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * MFT;
+    for (int64_t i = (int64_t)blockIdx.x * MFT + threadIdx.x; i < n; i += stride) out[i] = out[i] - b[i];
+}
+// ---- dispersive loss (mean_flow_matcher.py:27-39) on one (B, H) feature matrix z, from its Gram matrix G = z z^T -------------
+// dist_ij = G_ii + G_jj - 2 G_ij (clamped at 0; the diagonal is exactly 0); one wave per row: G <- dist, rowmax
+__global__ __launch_bounds__(MFT) void disp_dist_kernel(float* __restrict__ G, int B, float* __restrict__ rowmax) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float ni = G[(int64_t)row * B + row];
+    float mx = 0.f;
+    for (int j = lane; j < B; j += 64) {
+        const float nj = G[(int64_t)j * B + j];
+        float d = (ni + nj) - 2.0f * G[(int64_t)row * B + j];
+        d = (j == row || d < 0.f) ? 0.f : d;
+        mx = fmaxf(mx, d);
+        if (j != row) G[(int64_t)row * B + j] = d;      // the diagonal keeps the squared norm until every row has read it
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    if (lane == 0) rowmax[row] = mx;
+}
+// scal[0] = max(rowmax) + 1e-8
+__global__ __launch_bounds__(MFT) void disp_max_kernel(const float* __restrict__ rowmax, int B, float* __restrict__ scal) {
+    float mx = 0.f;
+    for (int i = threadIdx.x; i < B; i += MFT) mx = fmaxf(mx, rowmax[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    __shared__ float ws[MFT / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) scal[0] = fmaxf(fmaxf(ws[0], ws[1]), fmaxf(ws[2], ws[3])) + 1e-8f;
+}
+// G <- e_ij = exp(-(dist_ij / M') / tau) (diagonal: exp(0) = 1), rowsum_i = sum_j e_ij
+__global__ __launch_bounds__(MFT) void disp_exp_kernel(float* __restrict__ G, int B, const float* __restrict__ scal, float tau, float* __restrict__ rowsum) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= B) return;
+    const float M = scal[0];
+    float s = 0.f;
+    for (int j = lane; j < B; j += 64) {
+        const float d = j == row ? 0.f : G[(int64_t)row * B + j];
+        const float e = expf(-(d / M) / tau);
+        G[(int64_t)row * B + j] = e;
+        s += e;
+    }
+    s = wave_sum(s);
+    if (lane == 0) rowsum[row] = s;
+}
+// scal[1] = S = mean_ij e_ij; total[0] += log(S)
+__global__ __launch_bounds__(MFT) void disp_log_kernel(const float* __restrict__ rowsum, int B, float* __restrict__ scal, float* __restrict__ total) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < B; i += MFT) s += (double)rowsum[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    __shared__ double ws[MFT / 64];
+    if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float S = (float)((((ws[0] + ws[1]) + (ws[2] + ws[3])) / (double)B) / (double)B);
+        scal[1] = S;
+        total[0] = total[0] + logf(S);
+    }
+}
+// d (w * log S) / d z_i = 4 c (rowsum_i z_i - (E z)_i),  c = -w / (M' tau B^2 S)
+__global__ __launch_bounds__(MFT) void disp_grad_kernel(const float* __restrict__ z, const float* __restrict__ ez, const float* __restrict__ rowsum,
+                                                       const float* __restrict__ scal, float w, float tau, int B, int H, float* __restrict__ dz) {
+    const int64_t n = (int64_t)B * H, stride = (int64_t)gridDim.x * MFT;
+    const float c = -w / (scal[0] * tau * (float)B * (float)B * scal[1]);
+    for (int64_t i = (int64_t)blockIdx.x * MFT + threadIdx.x; i < n; i += stride) {
+        const int row = (int)(i / H);
+        dz[i] = 4.0f * c * (rowsum[row] * z[i] - ez[i]);
+    }
+}
+__global__ void mf_addw_kernel(float* __restrict__ losses, int dst, int src, float w, int keep) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const float base = losses[dst];
+        losses[keep] = base;
+        losses[dst] = base + w * losses[src];
+    }
+}
+
 inline unsigned mfgrid(int64_t n) {
     const int64_t b = (n + MFT - 1) / MFT;
     return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
@@ -1029,6 +1110,7 @@ struct MfTrainWs {
     float *xd0, *xd1, *xcd, *u1d, *sd, *dudt;                      // tangent pass (B rows)
     float *z0, *ZZ, *v, *u0, *rows, *wrow;
     float *vpred, *vnet, *DV, *rows2, *wrow2, *mrow1, *mrow2;      // improved MeanFlow
+    float *dispG, *dispEZ, *dispD, *dispRow, *dispSum, *dispScal;    // dispersive term: (B,B) Gram / exp matrix, E.z, per-level gradients (L,B,H)
     float *DU, *DX, *dz0, *dZZ, *dxa, *dxb, *dzt, *dtc, *dtmp, *dA1;
     StackWs dec, senc;
     CnnWs cnn;
@@ -1060,6 +1142,10 @@ MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const 
     s.S = c.take((L ? L : 1) * E * B * FF);
     s.xd0 = c.take(B * H); s.xd1 = c.take(B * H); s.xcd = c.take(B * H); s.u1d = c.take(B * FF); s.sd = c.take(B * FF); s.dudt = c.take(B * D);
     s.z0 = c.take(B * D); s.ZZ = c.take(2 * B * D); s.v = c.take(B * D); s.u0 = c.take(B * D); s.rows = c.take(B); s.wrow = c.take(B);
+    if (cfg.dispersive_loss_weight > 0.f && L > 0 && B > 1) {
+        s.dispG = c.take(B * B); s.dispEZ = c.take(B * H); s.dispD = c.take(L * B * H);
+        s.dispRow = c.take(B); s.dispSum = c.take(B); s.dispScal = c.take(4);
+    }
     if (imf) {
         s.vpred = c.take(B * D); s.vnet = c.take(B * D); s.DV = c.take(B * D);
         s.rows2 = c.take(B); s.wrow2 = c.take(B); s.mrow1 = c.take(B); s.mrow2 = c.take(B);
@@ -1127,7 +1213,9 @@ int mf_tangent_fwd(const MfCtx& c, const float* dz, const float* dtc) {
     return gemm_f32(lin(xd, H, w->u_w, H, nullptr, s.dudt, D, B, D, H, VITA_ACT_NONE), c.st);
 }
 // input-gradient chain of evaluation e from DU(e); leaves DX(l, e) for every l, dU1 in U1(l, e); dx = resid + DX(0,e) . W_in
-int mf_chain_bwd(const MfCtx& c, int e, float* dx, int64_t ld_dx, const float* resid, int64_t ld_resid, const float* dv = nullptr) {
+// extra: NULL, or (L, B, H) additive gradients of the layer outputs x_1..x_L of this evaluation (the dispersive term)
+int mf_chain_bwd(const MfCtx& c, int e, float* dx, int64_t ld_dx, const float* resid, int64_t ld_resid, const float* dv = nullptr,
+                 const float* extra = nullptr) {
     const vita_meanflow_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, B = c.B, L = w->L;
     VITA_TRY(gemm_f32(dgrad(c.DU(e), D, w->u_w, H, c.DX(L, e), H, B, H, D), c.st));
@@ -1137,6 +1225,7 @@ int mf_chain_bwd(const MfCtx& c, int e, float* dx, int64_t ld_dx, const float* r
         VITA_TRY(gemm_f32(a, c.st));
     }
     for (int l = L - 1; l >= 0; --l) {
+        if (extra) VITA_TRY(launch_axpy(extra + (size_t)l * c.bh(), c.DX(l + 1, e), (int64_t)B * H, c.st));   // x_{l+1} is internal_features[l]
         vita_linear_args a = dgrad(c.DX(l + 1, e), H, w->fc2_w[l], FF, c.U1(l, e), FF, B, FF, H);        // dU1 = (dY . W2) * silu'(U1), in place
         a.act = VITA_ACT_SILU; a.act_grad_z = c.U1(l, e); a.ld_act_grad_z = FF;
         VITA_TRY(gemm_f32(a, c.st));
@@ -1275,6 +1364,29 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         hipLaunchKernelGGL(mf_mean_kernel, dim3(1), dim3(MFT), 0, st, s.rows, B, losses + VITA_MF_LOSS_FLOW);
         VITA_CHECK_HIP(hipGetLastError());
     }
+    // dispersive term on the hidden layers' outputs at (z_t, t, r) — evaluation 0's own activations                 :185-195
+    const bool disp = cfg->dispersive_loss_weight > 0.f && L > 0 && B > 1;
+    VITA_REQUIRE(!(cfg->dispersive_loss_weight > 0.f) || cfg->dispersive_loss_tau > 0.f, "%s: dispersive_loss_tau must be > 0", who);
+    if (disp) {
+        for (int l = 0; l < L; ++l) {
+            const float* z = mc.Xs(l + 1, 0);
+            VITA_TRY(gemm_f32(lin(z, H, z, H, nullptr, s.dispG, B, B, B, H, VITA_ACT_NONE), st));
+            hipLaunchKernelGGL(disp_dist_kernel, dim3((B + 3) / 4), dim3(MFT), 0, st, s.dispG, B, s.dispRow);
+            hipLaunchKernelGGL(disp_max_kernel, dim3(1), dim3(MFT), 0, st, s.dispRow, B, s.dispScal);
+            hipLaunchKernelGGL(disp_exp_kernel, dim3((B + 3) / 4), dim3(MFT), 0, st, s.dispG, B, s.dispScal, cfg->dispersive_loss_tau, s.dispSum);
+            hipLaunchKernelGGL(disp_log_kernel, dim3(1), dim3(MFT), 0, st, s.dispSum, B, s.dispScal, losses + VITA_MF_LOSS_DISPERSIVE);
+            VITA_CHECK_HIP(hipGetLastError());
+            if (grads) {
+                VITA_TRY(gemm_f32(dgrad(s.dispG, B, z, H, s.dispEZ, H, B, H, B), st));      // E . z
+                hipLaunchKernelGGL(disp_grad_kernel, dim3(mfgrid((int64_t)B * H)), dim3(MFT), 0, st, z, s.dispEZ, s.dispSum, s.dispScal,
+                                   cfg->dispersive_loss_weight, cfg->dispersive_loss_tau, B, H, s.dispD + (size_t)l * B * H);
+                VITA_CHECK_HIP(hipGetLastError());
+            }
+        }
+        hipLaunchKernelGGL(mf_addw_kernel, dim3(1), dim3(64), 0, st, losses, (int)VITA_MF_LOSS_FLOW, (int)VITA_MF_LOSS_DISPERSIVE, cfg->dispersive_loss_weight,
+                           (int)VITA_MF_LOSS_FLOW_BASE);
+        VITA_CHECK_HIP(hipGetLastError());
+    }
     // MeanFlow sampler with grad                                                  mean_flow_matcher.py:201-233
     auto hstep = [&](int k) { return (float)((1.0 - (double)k / (double)K) - (1.0 - (double)(k + 1) / (double)K)); };
     if (do_sample) {
@@ -1340,9 +1452,12 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     else
         hipLaunchKernelGGL(mf_loss_bwd_kernel, dim3(mfgrid((int64_t)B * D)), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.hv, s.wrow, B, D, mc.DU(0));
     VITA_CHECK_HIP(hipGetLastError());
-    VITA_TRY(mf_chain_bwd(mc, 0, s.dzt, D, nullptr, 0, imf ? s.DV : nullptr));
+    VITA_TRY(mf_chain_bwd(mc, 0, s.dzt, D, nullptr, 0, imf ? s.DV : nullptr, disp ? s.dispD : nullptr));
     // conditioning gradients, eval 0: per row, dtc[b] = DX(0,0)[b] - DX(L,0)[b]  (sum over layers of d x_cond telescopes)
     hipLaunchKernelGGL(mf_sub_kernel, dim3(mfgrid((int64_t)B * H)), dim3(MFT), 0, st, mc.DX(0, 0), mc.DX(L, 0), s.dtc, (int64_t)B * H);
+    // the gradients injected at x_1..x_{L-1} enter d x_l but are not part of any d x_cond: take them out of the telescoped sum
+    for (int l = 0; disp && l + 1 < L; ++l)
+        hipLaunchKernelGGL(mf_sub_inplace_kernel, dim3(mfgrid((int64_t)B * H)), dim3(MFT), 0, st, s.dtc, s.dispD + (size_t)l * B * H, (int64_t)B * H);
     VITA_CHECK_HIP(hipGetLastError());
     if (do_sample) {
         const float* dxn = dpred;

@@ -153,11 +153,9 @@ class MeanFlowMatcher(_InferenceOnlyMatcher):
     `vita_amd.ops.MeanFlowNetHandle` (SimpleMeanFlowNet).  Training: the MeanFlow loss (JVP target + adaptive L2 loss, :164-183) and the
     improved-MeanFlow loss (use_imf: no-grad v-head tangent, compound velocity, auxiliary v loss, :137-163) run inside the
     policy's fused MeanFlow step (vita_compute_loss_meanflow_f32) with the (t, r) draw of `sample_t_r` made here on the host as
-    in the reference; the dispersive term (dispersive_loss_weight > 0) is not built."""
+    in the reference, and so does the dispersive term on the hidden layers' outputs (dispersive_loss_weight > 0, :27-39, 185-195)."""
 
-    @property
-    def inference_only(self) -> bool:
-        return float(self.dispersive_loss_weight) > 0.0
+    inference_only = False
 
     def sample_t_r(self, batch_size, device):
         """mean_flow_matcher.py:87-107, statement for statement (torch's generators, as in the reference)."""
@@ -180,7 +178,7 @@ class MeanFlowMatcher(_InferenceOnlyMatcher):
 
     def compute_loss(self, model, target, start=None, **kwargs):
         raise NotImplementedError("MeanFlowMatcher.compute_loss on its own is not exposed: the MeanFlow loss runs inside "
-                                  "VitaPolicy.compute_loss (vita_compute_loss_meanflow_f32); the dispersive term is not built")
+                                  "VitaPolicy.compute_loss (vita_compute_loss_meanflow_f32)")
 
     def sample(self, model: "ops.MeanFlowNetHandle", shape, device, num_steps=None, return_traces=False, start=None, **kwargs):
         """mean_flow_matcher.py:201-233."""

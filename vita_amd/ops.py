@@ -924,7 +924,8 @@ class MeanFlowPolicyHandle:
 def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_latents: bool = True, consistency_weight: float = 1.0,
                          enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, adaptive_loss_gamma: float = 0.5,
                          adaptive_loss_c: float = 1e-3, use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01,
-                         aux_v_loss_weight: float = 1.0) -> "L.MeanFlowLossConfig":
+                         aux_v_loss_weight: float = 1.0, dispersive_loss_weight: float = 0.0,
+                         dispersive_loss_tau: float = 1.0) -> "L.MeanFlowLossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")
     c = L.MeanFlowLossConfig()
@@ -932,6 +933,7 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
     c.consistency_weight, c.enc_recon_weight, c.flow_recon_weight = consistency_weight, enc_recon_weight, flow_recon_weight
     c.adaptive_loss_gamma, c.adaptive_loss_c = adaptive_loss_gamma, adaptive_loss_c
     c.use_imf, c.norm_p, c.norm_eps, c.aux_v_loss_weight = int(use_imf), norm_p, norm_eps, aux_v_loss_weight
+    c.dispersive_loss_weight, c.dispersive_loss_tau = dispersive_loss_weight, dispersive_loss_tau
     return c
 
 

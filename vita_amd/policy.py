@@ -332,7 +332,9 @@ class VitaPolicy(nn.Module):
                                                     flow_recon_weight=float(self.flow_action_recon_weight),
                                                     adaptive_loss_gamma=float(self.FM.adaptive_loss_gamma), use_imf=bool(self.FM.use_imf),
                                                     norm_p=float(self.FM.norm_p), norm_eps=float(self.FM.norm_eps),
-                                                    aux_v_loss_weight=float(self.FM.aux_v_loss_weight))
+                                                    aux_v_loss_weight=float(self.FM.aux_v_loss_weight),
+                                                    dispersive_loss_weight=float(self.FM.dispersive_loss_weight),
+                                                    dispersive_loss_tau=float(self.FM.dispersive_loss_tau))
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -576,6 +578,10 @@ class VitaPolicy(nn.Module):
             metrics = {"imf_loss": vals[5], "aux_v_loss": vals[6], "imf_mse": vals[7], "aux_v_mse": vals[8], "loss": vals[1], "flow_loss": vals[1]}
         else:
             metrics = {"meanflow_loss": vals[1], "loss": vals[1], "flow_loss": vals[1]}
+        if self._mf_cfg.dispersive_loss_weight > 0:     # :188-195; 'meanflow_loss' was read before the dispersive term was added
+            metrics["dispersive_loss"] = vals[9]
+            if not self.FM.use_imf and obs_features.shape[0] > 1:
+                metrics["meanflow_loss"] = vals[10]
         cfgv = self.config.policy.vita
         if cfgv.decode_flow_latents:
             if cfgv.consistency_weight > 0:
