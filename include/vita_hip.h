@@ -464,7 +464,7 @@ int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, in
  *   losses: device float[VITA_MF_LOSS_COUNT], indexed by VITA_MF_LOSS_*.
  *   grads: NULL = forward only; else every gradient buffer is overwritten (without use_imf the v head's with zeros: it takes no part).
  * use_imf = 1 is improved MeanFlow (flow_matcher.name = "improved_mean", :137-163).
- * Not built here: the variational encoder, freeze flags, contrastive terms. */
+ * Not built here: the variational encoder, contrastive terms. */
 typedef struct vita_meanflow_policy_weights {
     int32_t O;
     const float *obs_w, *obs_b;
@@ -483,6 +483,8 @@ typedef struct vita_meanflow_loss_config {
     float aux_v_loss_weight;
     float dispersive_loss_weight; /* > 0: + weight * sum over the hidden layers' outputs of dispersive_loss (:27-39, 185-195): */
     float dispersive_loss_tau;    /*   log(mean(exp(-cdist(z, z)^2 / (max(cdist^2).detach() + 1e-8) / tau))) over the batch */
+    int32_t freeze_encoder;       /* vita_policy.py:119: action latents without grad; with either flag the sampler block (:153) is skipped */
+    int32_t freeze_decoder;       /* vita_policy.py:174, 183: no decoder terms; the frozen module's gradients are written as zeros */
 } vita_meanflow_loss_config;
 /* losses of the MeanFlow step: device float[VITA_MF_LOSS_COUNT] */
 enum { VITA_MF_LOSS_TOTAL = 0, VITA_MF_LOSS_FLOW = 1 /* meanflow_loss, or imf_loss + aux_v_loss_weight * aux_v_loss */,

@@ -450,7 +450,8 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
                           consistency_weight: float = 1.0, enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5,
                           recon_loss_type: str = "l1", decode_flow_latents: bool = True, adaptive_loss_gamma: float = 0.5,
                           use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01, aux_v_loss_weight: float = 1.0,
-                          dispersive_loss_weight: float = 0.0, dispersive_loss_tau: float = 1.0):
+                          dispersive_loss_weight: float = 0.0, dispersive_loss_tau: float = 1.0,
+                          freeze_encoder: bool = False, freeze_decoder: bool = False):
     """VitaPolicy.compute_loss (vita_policy.py:112-189) with flow_matcher.name = 'mean' over SimpleMeanFlowNet: defaults
     otherwise (plain autoencoder, nothing frozen, no contrastive terms).  Returns (loss, metrics of 0-dim tensors)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
@@ -458,6 +459,8 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
     m = {}
     obs_latents = obs_encode(sd, obs_features)
     action_latents = action_encode(sd, gt_actions)
+    if freeze_encoder:                                                                             # :119
+        action_latents = action_latents.detach()
     if use_imf:
         flow_loss, fm = improved_mean_flow_loss(sd, obs_latents, action_latents, t, r, norm_p, norm_eps, aux_v_loss_weight)
         m.update(fm)
@@ -470,7 +473,7 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
         flow_loss = flow_loss + dispersive_loss_weight * dis
     loss = flow_loss
     m["flow_loss"] = flow_loss
-    if decode_flow_latents:                                                                        # :153-178
+    if decode_flow_latents and not freeze_encoder and not freeze_decoder:                          # :153-178
         pred = mean_flow_sample_grad(sd, obs_latents, num_steps)
         if consistency_weight > 0:
             cterm = F.mse_loss(pred, action_latents)
@@ -480,7 +483,7 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
             rterm = recon(simple_action_decode(sd, pred, T, A), gt_actions)
             m["flow_action_recon_loss"] = rterm
             loss = loss + flow_recon_weight * rterm
-    if enc_recon_weight > 0:                                                                       # :183-187
+    if enc_recon_weight > 0 and not freeze_decoder:                                                # :183-187
         rterm = recon(simple_action_decode(sd, action_latents, T, A), gt_actions)
         m["enc_action_recon_loss"] = rterm
         loss = loss + enc_recon_weight * rterm

@@ -85,7 +85,7 @@ def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf, dw,
 
 
 @pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma", "imf_default_dims_b64", "imf_norm",
-                                     "disp_default_dims_b64", "imf_disp"])
+                                     "disp_default_dims_b64", "imf_disp", "freeze_encoder", "freeze_decoder", "freeze_both", "imf_freeze_encoder"])
 def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     g = torch.Generator().manual_seed(31)
     kw, ck = {}, {}
@@ -93,6 +93,10 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
         kw.update(use_imf=True); ck.update(use_imf=True)
     if variant == "imf_norm":
         kw.update(norm_p=0.7, norm_eps=0.05, aux_v_loss_weight=0.3); ck.update(norm_p=0.7, norm_eps=0.05, aux_v_loss_weight=0.3)
+    if variant.endswith("freeze_encoder") or variant == "freeze_both":       # vita_policy.py:119, 142-143, 153
+        kw.update(freeze_encoder=True); ck.update(freeze_encoder=True)
+    if variant in ("freeze_decoder", "freeze_both"):                         # :174, 183
+        kw.update(freeze_decoder=True); ck.update(freeze_decoder=True)
     if "disp" in variant:
         kw.update(dispersive_loss_weight=0.5, dispersive_loss_tau=0.8); ck.update(dispersive_loss_weight=0.5, dispersive_loss_tau=0.8)
     if variant in ("default_dims_b64", "imf_default_dims_b64", "disp_default_dims_b64"):
@@ -209,3 +213,37 @@ def test_policy_mean_matcher_trains(dev):
             continue
         assert abs(met3[k] - m3[k].item()) <= 1e-5 * abs(m3[k].item()) + 1e-7, (k, met3[k], m3[k].item())
     loss3.backward()
+
+
+def test_policy_mean_matcher_freeze_encoder(dev):
+    """action_ae.freeze_encoder with the mean matcher through the policy: the sampler block is gated off (vita_policy.py:153), the
+    encoder gets zero gradients, metric keys as the reference emits them."""
+    from test_gpu_policy import small_cfg, make_policy, make_batch, hot_sd, oracle_features
+    cfg = small_cfg("cnn", matcher="mean")
+    cfg.policy.flow_net.name = "simple_mean_flow_net"
+    cfg.policy.flow_matcher.num_sampling_steps = 1
+    cfg.policy.action_ae.freeze_encoder = True
+    pol = make_policy(cfg, seed=5)
+    with torch.no_grad():
+        for k, p in pol.named_parameters():
+            if "output_layer" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(6)))
+    pol = pol.to(dev)
+    g = torch.Generator().manual_seed(7)
+    B = 9
+    batch = make_batch(cfg, B, g)
+    smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
+    t, r = smp.max(1)[0], smp.min(1)[0]
+    feats, acts = oracle_features(pol, batch, cfg)
+    sd64 = {k: v.double() for k, v in hot_sd(pol).items()}
+    ref, m = O.compute_loss_meanflow(sd64, feats.double(), acts.double(), t.double(), r.double(), 1, freeze_encoder=True)
+    nb = pol.normalize_targets(pol.normalize_inputs({k: v.to(dev) for k, v in batch.items()}))
+    pol.train()
+    loss, met = pol.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev))
+    assert set(met) == set(m) and "consistency_loss" not in met and "enc_action_recon_loss" in met, (sorted(met), sorted(m))
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    loss.backward()
+    for k, p in pol.hot_path_named_parameters():
+        if k.startswith("action_encoder."):
+            assert p.grad is None or p.grad.abs().max().item() == 0, k
+    assert pol.action_decoder.output_proj.weight.grad.abs().max().item() > 0 if hasattr(pol.action_decoder, "output_proj") else True

@@ -124,6 +124,7 @@ class MeanFlowLossConfig(C.Structure):
         ("adaptive_loss_gamma", C.c_float), ("adaptive_loss_c", C.c_float),
         ("use_imf", C.c_int32), ("norm_p", C.c_float), ("norm_eps", C.c_float), ("aux_v_loss_weight", C.c_float),
         ("dispersive_loss_weight", C.c_float), ("dispersive_loss_tau", C.c_float),
+        ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
     ]
 
 

@@ -1126,7 +1126,7 @@ MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const 
     Carver c(ws);
     MfTrainWs s{};
     // improved MeanFlow: one more (forward-only) evaluation slot and B more conditioning rows
-    const size_t K = cfg.decode_flow_latents ? (size_t)cfg.num_steps : 0, imf = cfg.use_imf ? 1 : 0, T = B + K + imf * B, E = 1 + K + imf;
+    const size_t K = (cfg.decode_flow_latents && !cfg.freeze_encoder && !cfg.freeze_decoder) ? (size_t)cfg.num_steps : 0, imf = cfg.use_imf ? 1 : 0, T = B + K + imf * B, E = 1 + K + imf;
     const size_t D = w.flow.D, H = w.flow.H, FF = w.flow.FF, L = w.flow.L;
     s.sk = c.take(kSplitkBytes / sizeof(float));
     s.consts = c.take(16);
@@ -1286,7 +1286,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     MfTrainWs s = carve_mf_train(workspace, *w, *cfg, (size_t)B);
     const vita_meanflow_weights* fw = &w->flow;
     const int D = fw->D, H = fw->H, FF = fw->FF, L = fw->L, OUT = w->dec.OUT;
-    const bool do_sample = cfg->decode_flow_latents != 0;
+    const bool fe = cfg->freeze_encoder != 0, fd = cfg->freeze_decoder != 0;          // vita_policy.py:119, 142-143, 153, 183
+    const bool do_sample = cfg->decode_flow_latents != 0 && !fe && !fd;
     const bool imf = cfg->use_imf != 0;
     VITA_REQUIRE(!imf || (fw->v_w && fw->v_b && (!grads || (grads->flow.v_w && grads->flow.v_b))), "%s: improved MeanFlow needs the v head", who);
     VITA_REQUIRE(!imf || (cfg->norm_eps > 0.f && cfg->aux_v_loss_weight >= 0.f), "%s: bad norm_eps / aux_v_loss_weight", who);
@@ -1295,7 +1296,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     const int K = do_sample ? cfg->num_steps : 0, Tc = B + K, T = Tc + (imf ? B : 0), Eg = 1 + K, E = Eg + (imf ? 1 : 0);
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
-    const bool dec_enc = cfg->enc_recon_weight > 0.f;
+    const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd;
     float* pred = s.ZZ;
     float* z1 = s.ZZ + (size_t)B * D;
     MfCtx mc{fw, &s, B, E, st};
@@ -1516,7 +1517,9 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     {
         StepWs es{};
         es.senc = s.senc; es.cnn = s.cnn;
-        if (w->enc.kind == VITA_ENC_SIMPLE)
+        if (fe)         // :119 the action latents were computed without grad
+            VITA_TRY(zero_encoder_grads(g.enc, st));
+        else if (w->enc.kind == VITA_ENC_SIMPLE)
             VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
                                w->enc.C, nullptr, 0, s.cs_part, st));
         else

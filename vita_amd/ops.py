@@ -925,7 +925,8 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
                          enc_recon_weight: float = 0.5, flow_recon_weight: float = 0.5, adaptive_loss_gamma: float = 0.5,
                          adaptive_loss_c: float = 1e-3, use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01,
                          aux_v_loss_weight: float = 1.0, dispersive_loss_weight: float = 0.0,
-                         dispersive_loss_tau: float = 1.0) -> "L.MeanFlowLossConfig":
+                         dispersive_loss_tau: float = 1.0, freeze_encoder: bool = False,
+                         freeze_decoder: bool = False) -> "L.MeanFlowLossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")
     c = L.MeanFlowLossConfig()
@@ -934,6 +935,7 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
     c.adaptive_loss_gamma, c.adaptive_loss_c = adaptive_loss_gamma, adaptive_loss_c
     c.use_imf, c.norm_p, c.norm_eps, c.aux_v_loss_weight = int(use_imf), norm_p, norm_eps, aux_v_loss_weight
     c.dispersive_loss_weight, c.dispersive_loss_tau = dispersive_loss_weight, dispersive_loss_tau
+    c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
     return c
 
 

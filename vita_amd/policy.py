@@ -318,8 +318,7 @@ class VitaPolicy(nn.Module):
                                          gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype],
                                          fm_kind=int(self.FM.kind), fm_sigma=float(self.FM.sigma))
         if self.mean_flow and not self.inference_only:      # MeanFlow training: the fused MeanFlow step's branches
-            bad = [n for n, on in (("action_ae.use_variational", self.use_action_vae), ("action_ae.freeze_encoder", self.freeze_action_encoder),
-                                   ("action_ae.freeze_decoder", self.freeze_action_decoder),
+            bad = [n for n, on in (("action_ae.use_variational", self.use_action_vae),
                                    ("vita.enc_contrastive_weight", self.enc_contrastive_weight > 0),
                                    ("vita.flow_contrastive_weight", self.flow_contrastive_weight > 0)) if on]
             if bad:
@@ -334,7 +333,9 @@ class VitaPolicy(nn.Module):
                                                     norm_p=float(self.FM.norm_p), norm_eps=float(self.FM.norm_eps),
                                                     aux_v_loss_weight=float(self.FM.aux_v_loss_weight),
                                                     dispersive_loss_weight=float(self.FM.dispersive_loss_weight),
-                                                    dispersive_loss_tau=float(self.FM.dispersive_loss_tau))
+                                                    dispersive_loss_tau=float(self.FM.dispersive_loss_tau),
+                                                    freeze_encoder=bool(self.freeze_action_encoder),
+                                                    freeze_decoder=bool(self.freeze_action_decoder))
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -583,12 +584,13 @@ class VitaPolicy(nn.Module):
             if not self.FM.use_imf and obs_features.shape[0] > 1:
                 metrics["meanflow_loss"] = vals[10]
         cfgv = self.config.policy.vita
-        if cfgv.decode_flow_latents:
+        fe, fd = self.freeze_action_encoder, self.freeze_action_decoder
+        if cfgv.decode_flow_latents and not fe and not fd:
             if cfgv.consistency_weight > 0:
                 metrics["consistency_loss"] = vals[2]
             if self.flow_action_recon_weight > 0:
                 metrics["flow_action_recon_loss"] = vals[3]
-        if self.enc_action_recon_weight > 0:
+        if self.enc_action_recon_weight > 0 and not fd:
             metrics["enc_action_recon_loss"] = vals[4]
         return loss, metrics
 
