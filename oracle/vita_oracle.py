@@ -451,7 +451,8 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
                           recon_loss_type: str = "l1", decode_flow_latents: bool = True, adaptive_loss_gamma: float = 0.5,
                           use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01, aux_v_loss_weight: float = 1.0,
                           dispersive_loss_weight: float = 0.0, dispersive_loss_tau: float = 1.0,
-                          freeze_encoder: bool = False, freeze_decoder: bool = False):
+                          freeze_encoder: bool = False, freeze_decoder: bool = False,
+                          enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0):
     """VitaPolicy.compute_loss (vita_policy.py:112-189) with flow_matcher.name = 'mean' over SimpleMeanFlowNet: defaults
     otherwise (plain autoencoder, nothing frozen, no contrastive terms).  Returns (loss, metrics of 0-dim tensors)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
@@ -473,12 +474,24 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
         flow_loss = flow_loss + dispersive_loss_weight * dis
     loss = flow_loss
     m["flow_loss"] = flow_loss
+    Bn = obs_latents.shape[0]
+    if enc_contrastive_weight > 0:                                                                 # :134-139
+        c = contrastive_loss(obs_latents.view(Bn, -1), action_latents.view(Bn, -1))
+        loss = loss + enc_contrastive_weight * c
+        m["enc_contrastive_loss"] = c
+    if freeze_encoder and freeze_decoder:                                                          # :142-143
+        m["loss"] = loss
+        return loss, m
     if decode_flow_latents and not freeze_encoder and not freeze_decoder:                          # :153-178
         pred = mean_flow_sample_grad(sd, obs_latents, num_steps)
         if consistency_weight > 0:
             cterm = F.mse_loss(pred, action_latents)
             loss = loss + consistency_weight * cterm
             m["consistency_loss"] = cterm
+        if flow_contrastive_weight > 0:                                                            # :167-172
+            c = contrastive_loss(obs_latents.view(Bn, -1), pred.view(Bn, -1))
+            loss = loss + flow_contrastive_weight * c
+            m["flow_contrastive_loss"] = c
         if flow_recon_weight > 0:
             rterm = recon(simple_action_decode(sd, pred, T, A), gt_actions)
             m["flow_action_recon_loss"] = rterm

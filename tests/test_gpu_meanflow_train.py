@@ -85,7 +85,8 @@ def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf, dw,
 
 
 @pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma", "imf_default_dims_b64", "imf_norm",
-                                     "disp_default_dims_b64", "imf_disp", "freeze_encoder", "freeze_decoder", "freeze_both", "imf_freeze_encoder"])
+                                     "disp_default_dims_b64", "imf_disp", "freeze_encoder", "freeze_decoder", "freeze_both", "imf_freeze_encoder",
+                                     "contrastive", "imf_contrastive_freeze_encoder"])
 def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     g = torch.Generator().manual_seed(31)
     kw, ck = {}, {}
@@ -97,6 +98,8 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
         kw.update(freeze_encoder=True); ck.update(freeze_encoder=True)
     if variant in ("freeze_decoder", "freeze_both"):                         # :174, 183
         kw.update(freeze_decoder=True); ck.update(freeze_decoder=True)
+    if "contrastive" in variant:                                             # :134-139, 167-172
+        kw.update(enc_contrastive_weight=0.3, flow_contrastive_weight=0.2); ck.update(enc_contrastive_weight=0.3, flow_contrastive_weight=0.2)
     if "disp" in variant:
         kw.update(dispersive_loss_weight=0.5, dispersive_loss_tau=0.8); ck.update(dispersive_loss_weight=0.5, dispersive_loss_tau=0.8)
     if variant in ("default_dims_b64", "imf_default_dims_b64", "disp_default_dims_b64"):
@@ -126,6 +129,10 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, **ck))
     assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item()), (losses[0].item(), loss.item())
     assert abs(losses[1].item() - m["flow_loss"].item()) <= 1e-5 * abs(m["flow_loss"].item())
+    if "contrastive" in variant:
+        assert abs(losses[11].item() - m["enc_contrastive_loss"].item()) <= 1e-5 * abs(m["enc_contrastive_loss"].item())
+        if "freeze" not in variant:
+            assert abs(losses[12].item() - m["flow_contrastive_loss"].item()) <= 1e-5 * abs(m["flow_contrastive_loss"].item())
     if "disp" in variant:
         assert abs(losses[9].item() - m["dispersive_loss"].item()) <= 1e-5 * abs(m["dispersive_loss"].item())
     if variant.startswith("imf"):

@@ -125,6 +125,7 @@ class MeanFlowLossConfig(C.Structure):
         ("use_imf", C.c_int32), ("norm_p", C.c_float), ("norm_eps", C.c_float), ("aux_v_loss_weight", C.c_float),
         ("dispersive_loss_weight", C.c_float), ("dispersive_loss_tau", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
+        ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
     ]
 
 
@@ -143,8 +144,8 @@ LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss",
               "flow_contrastive_loss", "action_kl_loss")
 LOSS_COUNT = 8
 MF_LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "imf_loss", "aux_v_loss",
-                 "imf_mse", "aux_v_mse", "dispersive_loss")
-MF_LOSS_COUNT = 12
+                 "imf_mse", "aux_v_mse", "dispersive_loss", "flow_loss_base", "enc_contrastive_loss", "flow_contrastive_loss")
+MF_LOSS_COUNT = 16
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
 SIGNATURES = {

@@ -1092,7 +1092,7 @@ __global__ __launch_bounds__(MFT) void disp_grad_kernel(const float* __restrict_
 __global__ void mf_addw_kernel(float* __restrict__ losses, int dst, int src, float w, int keep) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const float base = losses[dst];
-        losses[keep] = base;
+        if (keep >= 0) losses[keep] = base;
         losses[dst] = base + w * losses[src];
     }
 }
@@ -1112,6 +1112,7 @@ struct MfTrainWs {
     float *vpred, *vnet, *DV, *rows2, *wrow2, *mrow1, *mrow2;      // improved MeanFlow
     float *dispG, *dispEZ, *dispD, *dispRow, *dispSum, *dispScal;    // dispersive term: (B,B) Gram / exp matrix, E.z, per-level gradients (L,B,H)
     float *DU, *DX, *dz0, *dZZ, *dxa, *dxb, *dzt, *dtc, *dtmp, *dA1;
+    float *nce_enc, *nce_flow, *dz0c;                              // InfoNCE state and its d z0 (added to dz0 at the end)
     StackWs dec, senc;
     CnnWs cnn;
     size_t bytes;
@@ -1154,6 +1155,9 @@ MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const 
     s.DX = c.take((L + 1) * E * B * H);
     s.dz0 = c.take(B * D); s.dZZ = c.take(2 * B * D); s.dxa = c.take(B * D); s.dxb = c.take(B * D); s.dzt = c.take(B * D);
     s.dtc = c.take(T * H); s.dtmp = c.take(B * H); s.dA1 = c.take(T * H);
+    if (cfg.enc_contrastive_weight > 0.f) s.nce_enc = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
+    if (K > 0 && cfg.flow_contrastive_weight > 0.f) s.nce_flow = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
+    if (s.nce_enc || s.nce_flow) s.dz0c = c.take(B * D);
     s.dec = carve_stack(c, stack_of(w.dec), 2 * B, true);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, true);
     else s.cnn = carve_cnn(c, w.enc, B, true);
@@ -1269,7 +1273,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     VITA_REQUIRE(w->flow.D == w->dec.D && w->flow.D == w->enc.D && w->dec.OUT == w->enc.T * w->enc.A, "%s: latent / action dims differ", who);
     VITA_REQUIRE(B >= 1 && obs_features && actions && t && r && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/r/losses", who);
     VITA_REQUIRE(!cfg->decode_flow_latents || cfg->num_steps >= 1, "%s: num_steps must be >= 1", who);
-    VITA_REQUIRE(cfg->consistency_weight >= 0.f && cfg->enc_recon_weight >= 0.f && cfg->flow_recon_weight >= 0.f && cfg->adaptive_loss_c > 0.f,
+    VITA_REQUIRE(cfg->consistency_weight >= 0.f && cfg->enc_recon_weight >= 0.f && cfg->flow_recon_weight >= 0.f && cfg->adaptive_loss_c > 0.f &&
+                     cfg->enc_contrastive_weight >= 0.f && cfg->flow_contrastive_weight >= 0.f,
                  "%s: bad loss weights", who);
     if (grads) {
         VITA_TRY(check_mfw(&grads->flow, "vita_compute_loss_meanflow_f32 (grads)"));
@@ -1297,12 +1302,16 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
     const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
     const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd;
+    const bool nce_enc = cfg->enc_contrastive_weight > 0.f;                           // vita_policy.py:134-139
+    const bool nce_flow = do_sample && cfg->flow_contrastive_weight > 0.f;            // :167-172
+    const float tau = cfg->temperature > 0.f ? cfg->temperature : 0.07f;
     float* pred = s.ZZ;
     float* z1 = s.ZZ + (size_t)B * D;
     MfCtx mc{fw, &s, B, E, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
-    const float seeds[4] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight};
-    VITA_TRY(launch_set_scalars(s.consts, seeds, 4, st));
+    const float seeds[6] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight, cfg->enc_contrastive_weight,
+                            cfg->flow_contrastive_weight};
+    VITA_TRY(launch_set_scalars(s.consts, seeds, 6, st));
     VITA_CHECK_HIP(hipMemsetAsync(losses, 0, sizeof(float) * VITA_MF_LOSS_COUNT, st));
 
     // ---- forward ------------------------------------------------------------------------------
@@ -1401,7 +1410,9 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
             VITA_TRY(gemm_f32(o, st));
         }
         if (do_cons) VITA_TRY(vita_mse_loss_fwd_f32(pred, z1, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_CONSISTENCY, st));
+        if (nce_flow) VITA_TRY(nce_forward(s.z0, D, pred, D, B, D, tau, losses + VITA_MF_LOSS_FLOW_CONTRASTIVE, s.nce_flow, st));
     }
+    if (nce_enc) VITA_TRY(nce_forward(s.z0, D, z1, D, B, D, tau, losses + VITA_MF_LOSS_ENC_CONTRASTIVE, s.nce_enc, st));
     const Stack dec = stack_of(w->dec);
     const int r0 = dec_pred ? 0 : B;
     const int M = (dec_pred ? B : 0) + (dec_enc ? B : 0);
@@ -1416,6 +1427,13 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     const float wsum[5] = {0.f, 1.0f, do_cons ? cfg->consistency_weight : 0.f, dec_pred ? cfg->flow_recon_weight : 0.f,
                            dec_enc ? cfg->enc_recon_weight : 0.f};
     VITA_TRY(launch_weighted_sum(losses, wsum, 5, losses + VITA_LOSS_TOTAL, st));
+    if (nce_enc)
+        hipLaunchKernelGGL(mf_addw_kernel, dim3(1), dim3(64), 0, st, losses, (int)VITA_MF_LOSS_TOTAL, (int)VITA_MF_LOSS_ENC_CONTRASTIVE,
+                           cfg->enc_contrastive_weight, -1);
+    if (nce_flow)
+        hipLaunchKernelGGL(mf_addw_kernel, dim3(1), dim3(64), 0, st, losses, (int)VITA_MF_LOSS_TOTAL, (int)VITA_MF_LOSS_FLOW_CONTRASTIVE,
+                           cfg->flow_contrastive_weight, -1);
+    VITA_CHECK_HIP(hipGetLastError());
     if (!grads) return VITA_OK;
 
     // ---- backward -----------------------------------------------------------------------------
@@ -1446,6 +1464,9 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     float* dpred = s.dZZ;
     float* dz1 = s.dZZ + (size_t)B * D;
     if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
+    // InfoNCE terms: d pred / d z1 join dZZ now; their d z0 waits in dz0c (the sampler's first step overwrites dz0)
+    if (nce_flow) VITA_TRY(nce_backward(B, D, tau, s.consts + 5, s.dz0c, D, 0, dpred, D, 1, s.nce_flow, st));
+    if (nce_enc) VITA_TRY(nce_backward(B, D, tau, s.consts + 4, s.dz0c, D, nce_flow ? 1 : 0, dz1, D, 1, s.nce_enc, st));
     // MeanFlow loss -> DU(0); primal chain of evaluation 0 -> d z_t
     if (imf)
         hipLaunchKernelGGL(imf_loss_bwd_kernel, dim3(mfgrid((int64_t)B * D)), dim3(MFT), 0, st, s.u0, s.v, s.dudt, s.vpred, s.hv, s.wrow, s.wrow2, B, D,
@@ -1477,6 +1498,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     }
     // z_t = t*x0 + (1-t)*x1 (v is detached): d x1 += (1-t) d z_t, d x0 += t d z_t
     VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dzt, nullptr, t, nullptr, nullptr, dz1, s.dz0, B, D, 1, st));
+    if (nce_enc || nce_flow) VITA_TRY(launch_axpy(s.dz0c, s.dz0, (int64_t)B * D, st));
     // weight gradients over the stacked E*B rows
     {
         const int R = Eg * B;      // the forward-only slot of improved MeanFlow carries no gradient

@@ -926,7 +926,8 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
                          adaptive_loss_c: float = 1e-3, use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01,
                          aux_v_loss_weight: float = 1.0, dispersive_loss_weight: float = 0.0,
                          dispersive_loss_tau: float = 1.0, freeze_encoder: bool = False,
-                         freeze_decoder: bool = False) -> "L.MeanFlowLossConfig":
+                         freeze_decoder: bool = False, enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
+                         temperature: float = 0.07) -> "L.MeanFlowLossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")
     c = L.MeanFlowLossConfig()
@@ -936,13 +937,14 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
     c.use_imf, c.norm_p, c.norm_eps, c.aux_v_loss_weight = int(use_imf), norm_p, norm_eps, aux_v_loss_weight
     c.dispersive_loss_weight, c.dispersive_loss_tau = dispersive_loss_weight, dispersive_loss_tau
     c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
+    c.enc_contrastive_weight, c.flow_contrastive_weight, c.temperature = enc_contrastive_weight, flow_contrastive_weight, temperature
     return c
 
 
 def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, r: Tensor, *,
                           grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None) -> Tensor:
     """VitaPolicy.compute_loss with the MeanFlow matcher (+ backward when `grads` is given): vita_compute_loss_meanflow_f32.
-    Returns losses (12,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss).  No host sync."""
+    Returns losses (16,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss).  No host sync."""
     lib = L.load()
     obs_features = _rows(obs_features, "compute_loss_meanflow: obs_features")
     actions = _f32(actions, "compute_loss_meanflow: actions").contiguous()

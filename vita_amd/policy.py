@@ -318,9 +318,7 @@ class VitaPolicy(nn.Module):
                                          gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype],
                                          fm_kind=int(self.FM.kind), fm_sigma=float(self.FM.sigma))
         if self.mean_flow and not self.inference_only:      # MeanFlow training: the fused MeanFlow step's branches
-            bad = [n for n, on in (("action_ae.use_variational", self.use_action_vae),
-                                   ("vita.enc_contrastive_weight", self.enc_contrastive_weight > 0),
-                                   ("vita.flow_contrastive_weight", self.flow_contrastive_weight > 0)) if on]
+            bad = [n for n, on in (("action_ae.use_variational", self.use_action_vae),) if on]
             if bad:
                 self.inference_only = True      # sampler only; compute_loss raises and names the reason
                 self._mf_unsupported = bad
@@ -335,7 +333,9 @@ class VitaPolicy(nn.Module):
                                                     dispersive_loss_weight=float(self.FM.dispersive_loss_weight),
                                                     dispersive_loss_tau=float(self.FM.dispersive_loss_tau),
                                                     freeze_encoder=bool(self.freeze_action_encoder),
-                                                    freeze_decoder=bool(self.freeze_action_decoder))
+                                                    freeze_decoder=bool(self.freeze_action_decoder),
+                                                    enc_contrastive_weight=float(self.enc_contrastive_weight),
+                                                    flow_contrastive_weight=float(self.flow_contrastive_weight))
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -585,9 +585,13 @@ class VitaPolicy(nn.Module):
                 metrics["meanflow_loss"] = vals[10]
         cfgv = self.config.policy.vita
         fe, fd = self.freeze_action_encoder, self.freeze_action_decoder
+        if self.enc_contrastive_weight > 0:
+            metrics["enc_contrastive_loss"] = vals[11]
         if cfgv.decode_flow_latents and not fe and not fd:
             if cfgv.consistency_weight > 0:
                 metrics["consistency_loss"] = vals[2]
+            if self.flow_contrastive_weight > 0:
+                metrics["flow_contrastive_loss"] = vals[12]
             if self.flow_action_recon_weight > 0:
                 metrics["flow_action_recon_loss"] = vals[3]
         if self.enc_action_recon_weight > 0 and not fd:
