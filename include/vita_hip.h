@@ -464,7 +464,7 @@ int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, in
  *   losses: device float[VITA_MF_LOSS_COUNT], indexed by VITA_MF_LOSS_*.
  *   grads: NULL = forward only; else every gradient buffer is overwritten (without use_imf the v head's with zeros: it takes no part).
  * use_imf = 1 is improved MeanFlow (flow_matcher.name = "improved_mean", :137-163).
- * Not built here: the variational encoder. */
+ */
 typedef struct vita_meanflow_policy_weights {
     int32_t O;
     const float *obs_w, *obs_b;
@@ -488,18 +488,21 @@ typedef struct vita_meanflow_loss_config {
     float enc_contrastive_weight; /* vita_policy.py:134-139: InfoNCE(obs_latents, action_latents) */
     float flow_contrastive_weight;/* vita_policy.py:167-172: InfoNCE(obs_latents, sampled latents), inside the sampler block */
     float temperature;            /* <= 0: 0.07, the default of compute_contrastive_loss (contrastive_loss.py:5) */
+    float kl_weight;              /* variational encoder (w->enc.variational): action_kl_weight, vita_policy.py:146-150; `enc_noise` (B, D) is
+                                     the posterior's standard-normal draw, NULL = deterministic posterior (z = mean, KL = 0) */
 } vita_meanflow_loss_config;
 /* losses of the MeanFlow step: device float[VITA_MF_LOSS_COUNT] */
 enum { VITA_MF_LOSS_TOTAL = 0, VITA_MF_LOSS_FLOW = 1 /* meanflow_loss, or imf_loss + aux_v_loss_weight * aux_v_loss */,
        VITA_MF_LOSS_CONSISTENCY = 2, VITA_MF_LOSS_FLOW_RECON = 3, VITA_MF_LOSS_ENC_RECON = 4, VITA_MF_LOSS_IMF = 5, VITA_MF_LOSS_AUX_V = 6,
        VITA_MF_LOSS_IMF_MSE = 7, VITA_MF_LOSS_AUX_V_MSE = 8, VITA_MF_LOSS_DISPERSIVE = 9 /* unweighted sum over layers */,
        VITA_MF_LOSS_FLOW_BASE = 10 /* the matcher's loss before + weight * dispersive (its 'meanflow_loss' metric); written only with the dispersive term */,
-       VITA_MF_LOSS_ENC_CONTRASTIVE = 11, VITA_MF_LOSS_FLOW_CONTRASTIVE = 12, VITA_MF_LOSS_COUNT = 16 };
+       VITA_MF_LOSS_ENC_CONTRASTIVE = 11, VITA_MF_LOSS_FLOW_CONTRASTIVE = 12, VITA_MF_LOSS_ACTION_KL = 13,
+       VITA_MF_LOSS_COUNT = 16 };
 size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_weights* w, const vita_meanflow_loss_config* cfg, int32_t B);
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
-                                   const float* t, const float* r, int32_t B, float* losses, void* workspace, size_t workspace_bytes,
-                                   vita_stream_t stream);
+                                   const float* t, const float* r, const float* enc_noise, int32_t B, float* losses, void* workspace,
+                                   size_t workspace_bytes, vita_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -452,14 +452,19 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
                           use_imf: bool = False, norm_p: float = 1.0, norm_eps: float = 0.01, aux_v_loss_weight: float = 1.0,
                           dispersive_loss_weight: float = 0.0, dispersive_loss_tau: float = 1.0,
                           freeze_encoder: bool = False, freeze_decoder: bool = False,
-                          enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0):
+                          enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
+                          kl_weight: float = 0.0, enc_noise: Tensor | None = None):
     """VitaPolicy.compute_loss (vita_policy.py:112-189) with flow_matcher.name = 'mean' over SimpleMeanFlowNet: defaults
     otherwise (plain autoencoder, nothing frozen, no contrastive terms).  Returns (loss, metrics of 0-dim tensors)."""
     recon = F.l1_loss if recon_loss_type == "l1" else F.mse_loss
     T, A = gt_actions.shape[1], gt_actions.shape[2]
     m = {}
     obs_latents = obs_encode(sd, obs_features)
-    action_latents = action_encode(sd, gt_actions)
+    vae = is_variational(sd)
+    if vae:                                                                                        # :121
+        post_mean, post_logvar, action_latents = vae_cnn_action_encode(sd, gt_actions, enc_noise)
+    else:
+        action_latents = action_encode(sd, gt_actions)
     if freeze_encoder:                                                                             # :119
         action_latents = action_latents.detach()
     if use_imf:
@@ -482,6 +487,10 @@ def compute_loss_meanflow(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: T
     if freeze_encoder and freeze_decoder:                                                          # :142-143
         m["loss"] = loss
         return loss, m
+    if not freeze_encoder and vae and kl_weight > 0:                                               # :146-150
+        kl = torch.zeros((), dtype=obs_latents.dtype) if enc_noise is None else gaussian_kl(post_mean, post_logvar)
+        m["action_kl_loss"] = kl
+        loss = loss + kl_weight * kl
     if decode_flow_latents and not freeze_encoder and not freeze_decoder:                          # :153-178
         pred = mean_flow_sample_grad(sd, obs_latents, num_steps)
         if consistency_weight > 0:

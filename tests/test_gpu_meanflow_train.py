@@ -42,12 +42,13 @@ def nerr(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-30)).item()
 
 
-def run(ops, dev, sd, obs, actions, t, r, cfg):
+def run(ops, dev, sd, obs, actions, t, r, cfg, enc_noise=None):
     sdd = {k: v.to(dev).contiguous() for k, v in sd.items()}
     gsd = {k: torch.full_like(v, float("nan")) for k, v in sdd.items()}
     pw = ops.MeanFlowPolicyHandle(sdd, dev, pred_horizon=actions.shape[1], strict=True)
     gw = ops.MeanFlowPolicyHandle(gsd, dev, pred_horizon=actions.shape[1], strict=True)
-    losses = ops.compute_loss_meanflow(pw, cfg, obs.to(dev), actions.to(dev), t.to(dev), r.to(dev), grads=gw)
+    losses = ops.compute_loss_meanflow(pw, cfg, obs.to(dev), actions.to(dev), t.to(dev), r.to(dev), grads=gw,
+                                       enc_noise=enc_noise.to(dev) if enc_noise is not None else None)
     torch.cuda.synchronize()
     return losses.cpu(), {k: v.cpu() for k, v in gsd.items()}
 
@@ -86,7 +87,7 @@ def test_meanflow_step_golden_reference_autograd(ops, dev, gold, K, use_imf, dw,
 
 @pytest.mark.parametrize("variant", ["default_dims_b64", "l2_simple_encoder", "no_decode", "gamma", "imf_default_dims_b64", "imf_norm",
                                      "disp_default_dims_b64", "imf_disp", "freeze_encoder", "freeze_decoder", "freeze_both", "imf_freeze_encoder",
-                                     "contrastive", "imf_contrastive_freeze_encoder"])
+                                     "contrastive", "imf_contrastive_freeze_encoder", "vae", "vae_deterministic", "imf_vae_freeze_encoder"])
 def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     g = torch.Generator().manual_seed(31)
     kw, ck = {}, {}
@@ -107,7 +108,7 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     else:
         A, T, B, D, H, Lh, O_, enc, aeh, ael = 7, 16, 19, 64, 64, 3, 40, ("simple" if variant == "l2_simple_encoder" else "cnn"), 48, (2 if variant == "l2_simple_encoder" else 4)
     base = O.make_state_dict(O_, A, latent_dim=D, hidden_dim=64, num_layers=1, pred_horizon=T, ae_hidden=aeh, ae_layers=ael, time_embed_dim=16,
-                             seed=41, encoder_type=enc)
+                             seed=41, encoder_type=enc, variational="vae" in variant)
     sd = {k: v for k, v in base.items() if not k.startswith("flow_net.")}
     sd.update(O.make_meanflow_state_dict(D, H, Lh, 4.0, seed=42))
     K = 2
@@ -122,12 +123,20 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
     t, r = smp.max(1)[0], smp.min(1)[0]
     r[: B // 2] = t[: B // 2]
+    noise = None
+    if "vae" in variant:                                                     # vita_policy.py:120-121, 146-150
+        kw.update(kl_weight=0.01); ck.update(kl_weight=0.01)
+        if variant != "vae_deterministic":
+            noise = torch.randn(B, D, generator=g)
+            kw.update(enc_noise=noise.double())
     sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
     loss, m = O.compute_loss_meanflow(sd64, obs.double(), actions.double(), t.double(), r.double(), K, **kw)
     keys = list(sd64)
     gs = torch.autograd.grad(loss, [sd64[k] for k in keys], allow_unused=True)
-    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, **ck))
+    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=K, **ck), enc_noise=noise)
     assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item()), (losses[0].item(), loss.item())
+    if "action_kl_loss" in m:
+        assert abs(losses[13].item() - m["action_kl_loss"].item()) <= 1e-5 * abs(m["action_kl_loss"].item()) + 1e-12
     assert abs(losses[1].item() - m["flow_loss"].item()) <= 1e-5 * abs(m["flow_loss"].item())
     if "contrastive" in variant:
         assert abs(losses[11].item() - m["enc_contrastive_loss"].item()) <= 1e-5 * abs(m["enc_contrastive_loss"].item())
@@ -254,3 +263,42 @@ def test_policy_mean_matcher_freeze_encoder(dev):
         if k.startswith("action_encoder."):
             assert p.grad is None or p.grad.abs().max().item() == 0, k
     assert pol.action_decoder.output_proj.weight.grad.abs().max().item() > 0 if hasattr(pol.action_decoder, "output_proj") else True
+
+
+def test_policy_mean_matcher_variational_encoder(dev):
+    """action_ae.use_variational with the mean matcher through the policy (vita_policy.py:120-121, 146-150): training draws the
+    posterior (explicit eps here), eval is the deterministic posterior with KL 0."""
+    from test_gpu_policy import small_cfg, make_policy, make_batch, hot_sd, oracle_features
+    cfg = small_cfg("cnn", matcher="mean")
+    cfg.policy.flow_net.name = "simple_mean_flow_net"
+    cfg.policy.flow_matcher.num_sampling_steps = 1
+    cfg.policy.action_ae.use_variational = True
+    cfg.policy.action_ae.kl_weight = 1e-2
+    pol = make_policy(cfg, seed=8)
+    with torch.no_grad():
+        for k, p in pol.named_parameters():
+            if "output_layer" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(9)))
+    pol = pol.to(dev)
+    g = torch.Generator().manual_seed(10)
+    B = 9
+    batch = make_batch(cfg, B, g)
+    smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
+    t, r = smp.max(1)[0], smp.min(1)[0]
+    eps = torch.randn(B, pol.latent_dim, generator=g)
+    feats, acts = oracle_features(pol, batch, cfg)
+    sd64 = {k: v.double() for k, v in hot_sd(pol).items()}
+    nb = pol.normalize_targets(pol.normalize_inputs({k: v.to(dev) for k, v in batch.items()}))
+    pol.train()
+    loss, met = pol.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev), enc_noise=eps.to(dev))
+    ref, m = O.compute_loss_meanflow(sd64, feats.double(), acts.double(), t.double(), r.double(), 1, kl_weight=1e-2, enc_noise=eps.double())
+    assert set(met) == set(m), (sorted(met), sorted(m))
+    assert abs(loss.item() - ref.item()) <= 1e-5 * abs(ref.item())
+    assert abs(met["action_kl_loss"] - m["action_kl_loss"].item()) <= 1e-5 * abs(m["action_kl_loss"].item())
+    loss.backward()
+    assert pol.action_encoder.latent_proj.weight.grad.abs().max().item() > 0
+    pol.eval()
+    with torch.no_grad():
+        loss_e, met_e = pol.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev))
+    ref_e, _ = O.compute_loss_meanflow(sd64, feats.double(), acts.double(), t.double(), r.double(), 1, kl_weight=1e-2, enc_noise=None)
+    assert met_e["action_kl_loss"] == 0.0 and abs(loss_e.item() - ref_e.item()) <= 1e-5 * abs(ref_e.item())

@@ -126,6 +126,7 @@ class MeanFlowLossConfig(C.Structure):
         ("dispersive_loss_weight", C.c_float), ("dispersive_loss_tau", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
+        ("kl_weight", C.c_float),
     ]
 
 
@@ -144,7 +145,7 @@ LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss",
               "flow_contrastive_loss", "action_kl_loss")
 LOSS_COUNT = 8
 MF_LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "imf_loss", "aux_v_loss",
-                 "imf_mse", "aux_v_mse", "dispersive_loss", "flow_loss_base", "enc_contrastive_loss", "flow_contrastive_loss")
+                 "imf_mse", "aux_v_mse", "dispersive_loss", "flow_loss_base", "enc_contrastive_loss", "flow_contrastive_loss", "action_kl_loss")
 MF_LOSS_COUNT = 16
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks the header against
@@ -221,7 +222,7 @@ SIGNATURES = {
                                            C.c_size_t, c_fp]),
     "vita_compute_loss_meanflow_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowLossConfig), C.c_int32]),
     "vita_compute_loss_meanflow_f32": (C.c_int, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowPolicyWeights),
-                                                 C.POINTER(MeanFlowLossConfig), c_fp, C.c_int64, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp,
+                                                 C.POINTER(MeanFlowLossConfig), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp,
                                                  C.c_size_t, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),

@@ -1113,6 +1113,7 @@ struct MfTrainWs {
     float *dispG, *dispEZ, *dispD, *dispRow, *dispSum, *dispScal;    // dispersive term: (B,B) Gram / exp matrix, E.z, per-level gradients (L,B,H)
     float *DU, *DX, *dz0, *dZZ, *dxa, *dxb, *dzt, *dtc, *dtmp, *dA1;
     float *nce_enc, *nce_flow, *dz0c;                              // InfoNCE state and its d z0 (added to dz0 at the end)
+    float *params, *dparams, *kl_rows;                             // variational encoder: [mean | logvar] rows (B, 2D), their gradient, per-row KL
     StackWs dec, senc;
     CnnWs cnn;
     size_t bytes;
@@ -1158,6 +1159,7 @@ MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const 
     if (cfg.enc_contrastive_weight > 0.f) s.nce_enc = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
     if (K > 0 && cfg.flow_contrastive_weight > 0.f) s.nce_flow = c.take(nce_workspace_bytes((int)B, (int)D) / sizeof(float));
     if (s.nce_enc || s.nce_flow) s.dz0c = c.take(B * D);
+    if (w.enc.variational) { s.params = c.take(B * 2 * D); s.dparams = c.take(B * 2 * D); s.kl_rows = c.take(B); }
     s.dec = carve_stack(c, stack_of(w.dec), 2 * B, true);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, true);
     else s.cnn = carve_cnn(c, w.enc, B, true);
@@ -1261,15 +1263,16 @@ size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_wei
 
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
-                                   const float* t, const float* r, int32_t B, float* losses, void* workspace, size_t workspace_bytes,
-                                   vita_stream_t stream) {
+                                   const float* t, const float* r, const float* enc_noise, int32_t B, float* losses, void* workspace,
+                                   size_t workspace_bytes, vita_stream_t stream) {
     const char* who = "vita_compute_loss_meanflow_f32";
     VITA_REQUIRE(w && cfg, "%s: null weights / config", who);
     VITA_REQUIRE(w->O > 0 && w->obs_w && w->obs_b, "%s: bad obs_encoder", who);
     VITA_TRY(check_mfw(&w->flow, who));
     VITA_TRY(check_dec_weights(&w->dec, who));
     VITA_TRY(check_enc_weights(&w->enc, who));
-    VITA_REQUIRE(!w->enc.variational, "%s: the variational encoder is not built for the MeanFlow step", who);
+    VITA_REQUIRE(!w->enc.variational || w->enc.kind == VITA_ENC_CNN, "%s: the variational encoder is the CNN one", who);
+    VITA_REQUIRE(cfg->kl_weight >= 0.f, "%s: kl_weight must be >= 0", who);
     VITA_REQUIRE(w->flow.D == w->dec.D && w->flow.D == w->enc.D && w->dec.OUT == w->enc.T * w->enc.A, "%s: latent / action dims differ", who);
     VITA_REQUIRE(B >= 1 && obs_features && actions && t && r && losses && ldobs >= w->O, "%s: bad obs_features/actions/t/r/losses", who);
     VITA_REQUIRE(!cfg->decode_flow_latents || cfg->num_steps >= 1, "%s: num_steps must be >= 1", who);
@@ -1305,6 +1308,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     const bool nce_enc = cfg->enc_contrastive_weight > 0.f;                           // vita_policy.py:134-139
     const bool nce_flow = do_sample && cfg->flow_contrastive_weight > 0.f;            // :167-172
     const float tau = cfg->temperature > 0.f ? cfg->temperature : 0.07f;
+    const bool vae = w->enc.variational != 0;
+    const bool do_kl = vae && !fe && cfg->kl_weight > 0.f && enc_noise != nullptr;    // :142-150; deterministic posterior: kl() is zeros
     float* pred = s.ZZ;
     float* z1 = s.ZZ + (size_t)B * D;
     MfCtx mc{fw, &s, B, E, st};
@@ -1319,7 +1324,13 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     {
         StepWs es{};
         es.senc = s.senc; es.cnn = s.cnn;
-        VITA_TRY(encoder_fwd(w->enc, es, actions, z1, D, B, st));
+        if (vae) {                                                                                                    // vita_policy.py:121
+            VITA_TRY(encoder_fwd(w->enc, es, actions, s.params, 2 * D, B, st));
+            VITA_TRY(launch_gauss_sample(s.params, 2 * D, enc_noise, z1, D, B, D, st));
+            if (do_kl) VITA_TRY(vita_gaussian_kl_fwd_f32(s.params, 2 * D, s.params + D, 2 * D, B, D, s.kl_rows, losses + VITA_MF_LOSS_ACTION_KL, st));
+        } else {
+            VITA_TRY(encoder_fwd(w->enc, es, actions, z1, D, B, st));
+        }
     }
     hipLaunchKernelGGL(mf_prep_kernel, dim3((T + MFT - 1) / MFT), dim3(MFT), 0, st, t, r, s.tv, s.hv, s.ones, B, K, imf ? 1 : 0);
     VITA_CHECK_HIP(hipGetLastError());
@@ -1433,6 +1444,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     if (nce_flow)
         hipLaunchKernelGGL(mf_addw_kernel, dim3(1), dim3(64), 0, st, losses, (int)VITA_MF_LOSS_TOTAL, (int)VITA_MF_LOSS_FLOW_CONTRASTIVE,
                            cfg->flow_contrastive_weight, -1);
+    if (do_kl)
+        hipLaunchKernelGGL(mf_addw_kernel, dim3(1), dim3(64), 0, st, losses, (int)VITA_MF_LOSS_TOTAL, (int)VITA_MF_LOSS_ACTION_KL, cfg->kl_weight, -1);
     VITA_CHECK_HIP(hipGetLastError());
     if (!grads) return VITA_OK;
 
@@ -1544,7 +1557,10 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         else if (w->enc.kind == VITA_ENC_SIMPLE)
             VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
                                w->enc.C, nullptr, 0, s.cs_part, st));
-        else
+        else if (vae) {
+            VITA_TRY(launch_gauss_sample_bwd(s.params, 2 * D, enc_noise, dz1, D, do_kl ? cfg->kl_weight / (float)B : 0.f, s.dparams, 2 * D, B, D, st));
+            VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, s.dparams, 2 * D, B, s.cs_part, st));
+        } else
             VITA_TRY(cnn_bwd(w->enc, g.enc, s.cnn, actions, dz1, D, B, s.cs_part, st));
     }
     VITA_TRY(gemm_f32(wgrad(s.dz0, D, obs_features, ldobs, mut(g.obs_w), w->O, B, w->O, D), st));

@@ -927,7 +927,7 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
                          aux_v_loss_weight: float = 1.0, dispersive_loss_weight: float = 0.0,
                          dispersive_loss_tau: float = 1.0, freeze_encoder: bool = False,
                          freeze_decoder: bool = False, enc_contrastive_weight: float = 0.0, flow_contrastive_weight: float = 0.0,
-                         temperature: float = 0.07) -> "L.MeanFlowLossConfig":
+                         temperature: float = 0.07, kl_weight: float = 0.0) -> "L.MeanFlowLossConfig":
     if recon not in ("l1", "l2"):
         raise ValueError(f"Unsupported recon_loss_type: {recon}. Use 'l1' or 'l2'.")
     c = L.MeanFlowLossConfig()
@@ -938,11 +938,13 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
     c.dispersive_loss_weight, c.dispersive_loss_tau = dispersive_loss_weight, dispersive_loss_tau
     c.freeze_encoder, c.freeze_decoder = int(freeze_encoder), int(freeze_decoder)
     c.enc_contrastive_weight, c.flow_contrastive_weight, c.temperature = enc_contrastive_weight, flow_contrastive_weight, temperature
+    c.kl_weight = kl_weight
     return c
 
 
 def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, r: Tensor, *,
-                          grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None) -> Tensor:
+                          grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None,
+                          enc_noise: Optional[Tensor] = None) -> Tensor:
     """VitaPolicy.compute_loss with the MeanFlow matcher (+ backward when `grads` is given): vita_compute_loss_meanflow_f32.
     Returns losses (16,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss).  No host sync."""
     lib = L.load()
@@ -955,6 +957,12 @@ def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, a
         raise L.VitaHipError(f"compute_loss_meanflow: obs {tuple(obs_features.shape)} / actions {tuple(actions.shape)} / t {tuple(t.shape)} / "
                              f"r {tuple(r.shape)} do not match O={pw.O}, T={pw.T}, A={pw.A}")
     dev = obs_features.device
+    if enc_noise is not None:
+        if not pw.w.enc.variational:
+            raise L.VitaHipError("compute_loss_meanflow: enc_noise given but the action encoder is not variational")
+        enc_noise = _f32(enc_noise, "compute_loss_meanflow: enc_noise").contiguous()
+        if tuple(enc_noise.shape) != (B, pw.D):
+            raise L.VitaHipError(f"compute_loss_meanflow: enc_noise {tuple(enc_noise.shape)} is not (B, D) = ({B}, {pw.D})")
     if losses is None:
         losses = torch.empty(L.MF_LOSS_COUNT, dtype=torch.float32, device=dev)
     elif losses.numel() < L.MF_LOSS_COUNT:
@@ -963,7 +971,7 @@ def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, a
     ws = workspace(dev, nbytes)
     L.check(lib.vita_compute_loss_meanflow_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
                                                obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(), r.data_ptr(),
-                                               B, losses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(obs_features)),
+                                               enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(obs_features)),
             "vita_compute_loss_meanflow_f32")
     return losses
 

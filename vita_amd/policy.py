@@ -226,16 +226,16 @@ class _FusedMeanFlowLoss(torch.autograd.Function):
     """_FusedLoss for flow_matcher.name = 'mean': vita_compute_loss_meanflow_f32 (forward + backward in one call)."""
 
     @staticmethod
-    def forward(ctx, policy, obs_features, actions, t, r, *params):
+    def forward(ctx, policy, obs_features, actions, t, r, enc_noise, *params):
         pw, gw, gsd = policy._train_handles(stage=True)
-        losses = ops.compute_loss_meanflow(pw, policy._mf_cfg, obs_features.detach(), actions, t, r, grads=gw)
+        losses = ops.compute_loss_meanflow(pw, policy._mf_cfg, obs_features.detach(), actions, t, r, grads=gw, enc_noise=enc_noise)
         ctx.staged = [gsd[k] for k, _ in policy.hot_path_named_parameters()]
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
 
     @staticmethod
     def backward(ctx, gout, _):
-        return (None, None, None, None, None) + tuple(g * gout for g in ctx.staged)
+        return (None, None, None, None, None, None) + tuple(g * gout for g in ctx.staged)
 
 
 class VitaPolicy(nn.Module):
@@ -318,10 +318,6 @@ class VitaPolicy(nn.Module):
                                          gemm_bf16={"f32": 0, "bf16": 1, "bf16_all": 2}[self.gemm_dtype],
                                          fm_kind=int(self.FM.kind), fm_sigma=float(self.FM.sigma))
         if self.mean_flow and not self.inference_only:      # MeanFlow training: the fused MeanFlow step's branches
-            bad = [n for n, on in (("action_ae.use_variational", self.use_action_vae),) if on]
-            if bad:
-                self.inference_only = True      # sampler only; compute_loss raises and names the reason
-                self._mf_unsupported = bad
             self._mf_cfg = ops.meanflow_loss_config(num_steps=self.num_sampling_steps, recon=ae.recon_loss_type,
                                                     decode_flow_latents=bool(pol.vita.decode_flow_latents),
                                                     consistency_weight=float(pol.vita.consistency_weight),
@@ -335,7 +331,8 @@ class VitaPolicy(nn.Module):
                                                     freeze_encoder=bool(self.freeze_action_encoder),
                                                     freeze_decoder=bool(self.freeze_action_decoder),
                                                     enc_contrastive_weight=float(self.enc_contrastive_weight),
-                                                    flow_contrastive_weight=float(self.flow_contrastive_weight))
+                                                    flow_contrastive_weight=float(self.flow_contrastive_weight),
+                                                    kl_weight=float(self.action_kl_weight) if self.use_action_vae else 0.0)
         self._flat = self._flat_grad = None
         self._cache = {}
         self.bucket_ranges = None
@@ -509,7 +506,12 @@ class VitaPolicy(nn.Module):
                 t, r = self.FM.sample_t_r(obs_features.shape[0], obs_features.device)
             else:
                 r = pair_i if pair_i is not None else t
-            out = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r.to(torch.float32), grads=gw, losses=losses)
+            if self.use_action_vae and self.training and enc_noise is None:      # the posterior's draw (action_vae.py:227, dists.py:19-22)
+                enc_noise = torch.randn(obs_features.shape[0], self.latent_dim, device=obs_features.device)
+            elif not self.use_action_vae or not self.training:
+                enc_noise = None
+            out = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r.to(torch.float32), grads=gw, losses=losses,
+                                            enc_noise=enc_noise)
             for e in (grad_ready_events or ()):     # the MeanFlow step records no intermediate events: every bucket is ready at its end
                 if e is not None:
                     e.record(torch.cuda.current_stream(obs_features.device))
@@ -530,7 +532,7 @@ class VitaPolicy(nn.Module):
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
         if self.mean_flow:
-            return self._compute_loss_meanflow(obs_features, actions, t, pair_i)
+            return self._compute_loss_meanflow(obs_features, actions, t, pair_i, enc_noise)
         t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
                                                             actions, enc_noise, fm_noise)
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
@@ -560,19 +562,23 @@ class VitaPolicy(nn.Module):
             metrics["enc_action_recon_loss"] = vals[4]
         return loss, metrics
 
-    def _compute_loss_meanflow(self, obs_features, actions, t=None, r=None):
+    def _compute_loss_meanflow(self, obs_features, actions, t=None, r=None, enc_noise=None):
         """compute_loss for flow_matcher.name = 'mean' (mean_flow_matcher.py:109-199 inside vita_policy.py:112-189); metric keys
         as the reference emits them: FM's {'meanflow_loss', 'loss'} plus the policy's."""
         if t is None:
             t, r = self.FM.sample_t_r(obs_features.shape[0], obs_features.device)
         elif r is None:
             r = t
+        if self.use_action_vae and self.training and enc_noise is None:      # the posterior's draw (action_vae.py:227, dists.py:19-22)
+            enc_noise = torch.randn(obs_features.shape[0], self.latent_dim, device=obs_features.device)
+        elif not self.use_action_vae or not self.training:
+            enc_noise = None        # deterministic posterior: z = mean, KL = 0
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
             params = [p for _, p in self.hot_path_named_parameters()]
-            loss, losses = _FusedMeanFlowLoss.apply(self, obs_features, actions, t, r, *params)
+            loss, losses = _FusedMeanFlowLoss.apply(self, obs_features, actions, t, r, enc_noise, *params)
         else:
             pw, _, _ = self._train_handles()
-            losses = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r)
+            losses = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r, enc_noise=enc_noise)
             loss = losses[0]
         vals = losses.detach().cpu().tolist()
         if self.FM.use_imf:     # mean_flow_matcher.py:158-163, 197
@@ -587,6 +593,10 @@ class VitaPolicy(nn.Module):
         fe, fd = self.freeze_action_encoder, self.freeze_action_decoder
         if self.enc_contrastive_weight > 0:
             metrics["enc_contrastive_loss"] = vals[11]
+        if fe and fd:                                                                              # :142-143
+            return loss, metrics
+        if not fe and self.use_action_vae and self.action_kl_weight > 0:                           # :146-150
+            metrics["action_kl_loss"] = vals[13]
         if cfgv.decode_flow_latents and not fe and not fd:
             if cfgv.consistency_weight > 0:
                 metrics["consistency_loss"] = vals[2]
