@@ -15,9 +15,10 @@ from vita_amd.trainer import PolicyTrainer  # noqa: E402
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 dev = torch.device("cuda:0")
-for name in ("mean", "improved_mean"):
+for name, disp in (("mean", 0.0), ("improved_mean", 0.0), ("mean", 0.5)):
     cfg = default_config("hook_package")
     cfg.policy.flow_matcher.name = name
+    cfg.policy.flow_matcher.dispersive_loss_weight = disp
     cfg.policy.flow_matcher.num_sampling_steps = 1
     cfg.policy.flow_net.name = "simple_mean_flow_net"
     S, A = cfg.task.state_dim, cfg.task.action_dim
@@ -45,5 +46,5 @@ for name in ("mean", "improved_mean"):
         tr.train_step(batch, t=t, pair_i=r)
     torch.cuda.synchronize()
     el = time.perf_counter() - t0
-    print(f"{name}: B={B} ms_per_step={el * 1e3 / steps:.3f} samples_per_s={B * steps / el:.1f} loss={tr.metrics()['loss']:.6f}")
+    print(f"{name}{' + dispersive' if disp else ''}: B={B} ms_per_step={el * 1e3 / steps:.3f} samples_per_s={B * steps / el:.1f} loss={tr.metrics()['loss']:.6f}")
     del tr, pol
