@@ -181,10 +181,13 @@ def test_meanflow_training_losses_and_gradients_match_reference_autograd(golden_
     v = load(os.path.join(golden_dir, "meanflow_train.safetensors"))
     sd = {k[len("mf/sd/"):]: x for k, x in v.items() if k.startswith("mf/sd/")}
     obs, actions, t, r = (v["mf/" + k] for k in ("obs_features", "actions", "t", "r"))
-    for K, use_imf in ((1, False), (3, False), (1, True), (2, True)):
-        tag = f"mf/{'imf_' if use_imf else ''}K{K}"
+    # the last two cases carry the dispersive term (dispersive_loss_weight, dispersive_loss_tau; mean_flow_matcher.py:27-39, 185-195)
+    for K, use_imf, dw, tau in ((1, False, 0.0, 1.0), (3, False, 0.0, 1.0), (1, True, 0.0, 1.0), (2, True, 0.0, 1.0),
+                                (1, False, 0.5, 1.0), (2, True, 0.25, 0.7)):
+        tag = f"mf/{'imf_' if use_imf else ''}{'disp_' if dw > 0 else ''}K{K}"
         sdg = {k: x.clone().requires_grad_(True) for k, x in sd.items()}
-        loss, m = O.compute_loss_meanflow(sdg, obs, actions, t, r, K, use_imf=use_imf)
+        loss, m = O.compute_loss_meanflow(sdg, obs, actions, t, r, K, use_imf=use_imf, dispersive_loss_weight=dw, dispersive_loss_tau=tau)
+        assert ("dispersive_loss" in m) == (dw > 0)
         for k in m:
             close(m[k].detach().reshape(1), v[f"{tag}/loss/{k}"], 3e-6)
         keys = list(sdg)
