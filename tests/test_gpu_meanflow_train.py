@@ -308,3 +308,12 @@ def test_policy_mean_matcher_variational_encoder(dev):
         loss_e, met_e = pol.compute_loss(nb, t=t.to(dev), pair_i=r.to(dev))
     ref_e, _ = O.compute_loss_meanflow(sd64, feats.double(), acts.double(), t.double(), r.double(), 1, kl_weight=1e-2, enc_noise=None)
     assert met_e["action_kl_loss"] == 0.0 and abs(loss_e.item() - ref_e.item()) <= 1e-5 * abs(ref_e.item())
+    # and through the trainer (the posterior's draw made by loss_and_grads)
+    from vita_amd.trainer import PolicyTrainer
+    pol.train()
+    tr = PolicyTrainer(cfg, pol, dev, num_training_steps=20)
+    torch.manual_seed(1)
+    for _ in range(3):
+        tr.train_step(batch)
+    mm = tr.metrics()
+    assert all(v == v for v in mm.values()) and mm["action_kl_loss"] > 0, mm
