@@ -32,6 +32,101 @@ PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak
 TASKS = {"hook_package": (533, 21), "robomimic_square": (555, 7), "pusht": (514, 2), "thread_needle": (533, 21)}
 
 
+def self_launch(n: int) -> int:
+    """One child process per GPU with the torch.distributed.run environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*);
+    rank 0's stdout is relayed, the other ranks' goes to stderr.  Returns the first non-zero exit code, else 0."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    for pr in procs:
+        c = pr.wait()
+        rc = rc or c
+    return rc
+
+
+def cpu_baseline(args, sd, obs, K, A, fpc):
+    """the oracle (CPU restatement of the reference, torch CPU fp32; kind "port") on this box's host
+    cores: hook_package inference on a bounded row sample, pusht B=64 inference and one full pusht train step (forward,
+    autograd backward, clip 1.0, AdamW) -- each at all cores of this job's share and at 1 thread, 3 warm-ups + the median of
+    up to 10 timed iterations, the whole leg inside --cpu-seconds."""
+    import statistics
+    from oracle import vita_oracle as O   # the checker, timed here as the reported CPU baseline only
+    from vita_amd.synthetic import make_state_dict
+    ncores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    ncores = max(1, min(ncores, os.cpu_count() or 1))
+    deadline = time.perf_counter() + args.cpu_seconds
+
+    def med(fn, warm=3, iters=10):
+        ts = []
+        for i in range(warm + iters):
+            if ts and time.perf_counter() > deadline:
+                break
+            t0 = time.perf_counter()
+            fn()
+            if i >= warm or time.perf_counter() > deadline:
+                ts.append(time.perf_counter() - t0)
+        return statistics.median(ts), len(ts)
+
+    psd = make_state_dict(514, 2, seed=0)
+    g = torch.Generator().manual_seed(1)
+    pobs, pact = torch.randn(64, 514, generator=g), torch.randn(64, 16, 2, generator=g)
+    pt = torch.rand(64, generator=torch.Generator().manual_seed(2))
+    f_pusht = flops_per_chunk(514, 512, 512, 2048, 4, K, 512, 4, 32)
+
+    def pusht_train():
+        leaf = {k: v.clone().requires_grad_(True) for k, v in psd.items()}
+        loss, _ = O.compute_loss(leaf, pobs, pact, pt, K)
+        loss.backward()
+        grads = [p.grad for p in leaf.values()]
+        gn = torch.sqrt(sum((g_.double() ** 2).sum() for g_ in grads))
+        coef = min(1.0, 1.0 / (gn.item() + 1e-6))
+        with torch.no_grad():
+            for p_ in leaf.values():
+                O.adamw_step(p_, p_.grad * coef, torch.zeros_like(p_), torch.zeros_like(p_), 1, 1e-4)
+
+    out = {"unit": "action-chunks/s", "kind": "port", "cores": ncores, "cpu_model": cpu_model(), "torch": torch.__version__,
+           "host_cpus_visible": os.cpu_count(), "protocol": "3 warm-ups + median of <= 10 iterations per figure, time-boxed"}
+    legs = {}
+    for nthreads in (ncores, 1):
+        torch.set_num_threads(nthreads)
+        rows = args.cpu_rows if nthreads > 1 else max(64, args.cpu_rows // 4)
+        cobs = obs[:rows].cpu()
+        with torch.no_grad():
+            dt, n = med(lambda: O.generate_actions(sd, cobs, K, 16, A))
+            hp = {"chunks_per_s": round(rows / dt, 1), "rows": rows, "iters": n, "gflops": round(rows * fpc / dt / 1e9, 1)}
+            dt, n = med(lambda: O.generate_actions(psd, pobs, K, 16, 2))
+            pi = {"chunks_per_s": round(64 / dt, 1), "ms": round(dt * 1e3, 2), "iters": n, "gflops": round(64 * f_pusht / dt / 1e9, 1)}
+        dt, n = med(pusht_train, warm=1, iters=10)
+        ptn = {"samples_per_s": round(64 / dt, 1), "ms_per_step": round(dt * 1e3, 1), "iters": n}
+        legs[f"{nthreads}_threads"] = {"hook_package_inference": hp, "pusht_b64_inference": pi, "pusht_b64_train_step": ptn}
+    torch.set_num_threads(ncores)
+    out["value"] = legs[f"{ncores}_threads"]["hook_package_inference"]["chunks_per_s"]
+    out["sample"] = (f"hook_package generate_actions, {legs[f'{ncores}_threads']['hook_package_inference']['rows']} of the {obs.shape[0]} rows "
+                     f"(same weights / inputs, K={K}), {ncores} threads, median of {legs[f'{ncores}_threads']['hook_package_inference']['iters']}")
+    out["configs"] = legs
+    return out
+
+
+def cpu_model() -> str:
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,16 +141,25 @@ def main():
     ap.add_argument("--train-steps", type=int, default=0, help="timed training steps (0 = same as --steps)")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-large-batch", type=int, default=4096, help="N=1 only: side figures of the training step at this batch, fp32 and bf16 operands (0 = skip)")
-    ap.add_argument("--cpu-rows", type=int, default=512)
+    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the hook_package CPU-baseline sample at all cores")
+    ap.add_argument("--cpu-seconds", type=float, default=40.0, help="time box of the whole cpu_baseline leg")
+    ap.add_argument("--dry-launch", action="store_true", help="ranks print their launch environment as JSON and exit (no GPU touched): "
+                                                              "the CPU-side test of the N>1 self-launch")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver may call it: start N fresh rank processes (never re-exec this one; nothing
+        # here has touched the GPU yet), relay rank 0's line, fail if any rank fails
+        raise SystemExit(self_launch(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N>1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.dry_launch:
+        print(json.dumps({"rank": rank, "local_rank": local_rank, "world": world, "master_addr": os.environ.get("MASTER_ADDR"),
+                          "master_port": os.environ.get("MASTER_PORT"), "pid": os.getpid(), "ppid": os.getppid()}), flush=True)
+        return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
@@ -64,13 +168,13 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from oracle import vita_oracle as O   # weights generator + cpu_baseline leg only
     from vita_amd import ops, _lib
-    _lib.load()
+    from vita_amd.synthetic import make_state_dict
+    lib = _lib.load()
 
     obs_dim, A = TASKS[args.task]
     B, K = args.batch, args.ode_steps
-    sd = O.make_state_dict(obs_dim, A, hidden_dim=args.hidden, seed=0)
+    sd = make_state_dict(obs_dim, A, hidden_dim=args.hidden, seed=0)
     fw, dw = ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev)
     ow, ob = sd["obs_encoder.weight"].to(dev), sd["obs_encoder.bias"].to(dev)
     g = torch.Generator().manual_seed(1 + rank)
@@ -223,19 +327,23 @@ def main():
         e1.synchronize()
         return e0.elapsed_time(e1) * 1e-3 / reps
 
-    FC1 = f"fc1 gemm_f32_dma<256,128,32,3> {B}x{fw.FF}x{fw.H} bias+gelu_tanh"
     kernels = {}
+    dom = None
     if rank == 0:
         for name, (M, N, Kd, kw) in {
-            FC1: (B, fw.FF, fw.H, dict(act=_lib.ACT_GELU_TANH)),
-            f"fc2 gemm_f32_dma<64,128,64,3> {B}x{fw.H}x{fw.FF} bias+gate+resid": (B, fw.H, fw.FF, dict(gated=True)),
-            f"in_proj gemm_f32_dma<64,128,64,3> {B}x{fw.H}x{fw.D} bias": (B, fw.H, fw.D, dict()),
+            "fc1": (B, fw.FF, fw.H, dict(act=_lib.ACT_GELU_TANH)),
+            "fc2": (B, fw.H, fw.FF, dict(gated=True)),
+            "in_proj": (B, fw.H, fw.D, dict()),
         }.items():
             dt = time_linear(M, N, Kd, **kw)
+            cfg_ = (lib.vita_debug_last_gemm_config() or b"").decode() or "not the LDS-DMA family"   # what the call dispatched
+            epi = {"fc1": "bias+gelu_tanh", "fc2": "bias+gate+resid", "in_proj": "bias"}[name]
+            label = f"{name} {cfg_} {M}x{N}x{Kd} {epi}"
             fl = 2.0 * M * N * Kd
-            kernels[name] = {"avg_us": round(dt * 1e6, 2), "tflops": round(fl / dt / 1e12, 2),
-                             "frac_of_f32_mfma_peak": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-    dom = FC1
+            kernels[label] = {"avg_us": round(dt * 1e6, 2), "tflops": round(fl / dt / 1e12, 2),
+                              "frac_of_f32_mfma_peak": round(fl / dt / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+            if name == "fc1":
+                dom = label
 
     # ---- HBM-bound kernels (loss / elementwise / optimizer): achieved GB/s of algorithmic bytes against the 8 TB/s HBM3E peak
     hbm = {}
@@ -277,33 +385,21 @@ def main():
                          "frac_of_hbm_peak": round(nbytes / dt_ / 8e12, 4)}
         del xa, xb, hh, dyh, pp, gg, mm, vv, ee
 
-    traffic = None
+    # HBM bytes per fc1 launch from the PMC passes (tools/profile.sh -> profiles/traffic.json): a committed measurement, not
+    # taken in this run, so it is reported only for the shape it was taken on, with its source named
+    traffic, traffic_src = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("fc1_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            if tj.get("shape") == [B, fw.FF, fw.H]:
+                traffic, traffic_src = tj.get("fc1_hbm_bytes_per_launch"), f"{tj.get('source')} (PMC passes on shape {tj.get('shape')}, not this run)"
         except Exception:
             traffic = None
 
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        # the oracle (CPU restatement of the reference, torch CPU fp32) on a bounded row sample
-        nthreads = min(16, os.cpu_count() or 1)
-        torch.set_num_threads(nthreads)
-        rows = args.cpu_rows
-        cobs = obs[:rows].cpu()
-        with torch.no_grad():
-            O.generate_actions(sd, cobs, K, 16, A)
-            t0 = time.perf_counter()
-            n = 0
-            while True:
-                O.generate_actions(sd, cobs, K, 16, A)
-                n += 1
-                if time.perf_counter() - t0 > 12.0 or n >= 50:
-                    break
-            cdt = (time.perf_counter() - t0) / n
-        cpu = {"value": round(rows / cdt, 1), "unit": "action-chunks/s", "cores": nthreads, "kind": "port",
-               "sample": f"{n} passes of {rows} rows (same weights/inputs, K={K}), oracle/vita_oracle.generate_actions, torch {torch.__version__} CPU fp32"}
+        cpu = cpu_baseline(args, sd, obs, K, A, fpc)
 
     if rank == 0:
         line = {
@@ -326,7 +422,7 @@ def main():
                             "frac_of_f32_mfma_peak": round(lat_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
             "roofline": {"bound": "mfma", "kernel": dom,
                          "achieved": kernels[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic,
+                         "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic, "traffic_source": traffic_src,
                          "flops_per_launch": 2.0 * B * fw.FF * fw.H,
                          "avg_launch_us": kernels[dom]["avg_us"],
                          "timing": "HIP events around 20 back-to-back launches on the launch stream: includes the gap between "

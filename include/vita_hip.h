@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VITA_ABI_VERSION 1
+#define VITA_ABI_VERSION 2
 #define VITA_MAX_LAYERS 16
 
 typedef void* vita_stream_t; /* hipStream_t */
@@ -100,6 +100,9 @@ typedef struct vita_linear_args {
 
 int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream);
 size_t vita_splitk_workspace_bytes(void);
+/* diagnostic: the tile configuration "<BM,BN,BK,NS,KG> xcd RxC" that the calling thread's last LDS-DMA GEMM launch
+ * dispatched ("" if the last call took another kernel family); bench.py labels its roofline kernel with it */
+const char* vita_debug_last_gemm_config(void);
 
 /* ---------------------------------------------------------------------------------------
  * Weight descriptors: device pointers to the checkpoint tensors, unchanged.
@@ -463,6 +466,7 @@ int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, in
  *   t, r (B): the (t, r) draw of sample_t_r (:87-107), made by the caller.
  *   losses: device float[VITA_MF_LOSS_COUNT], indexed by VITA_MF_LOSS_*.
  *   grads: NULL = forward only; else every gradient buffer is overwritten (without use_imf the v head's with zeros: it takes no part).
+ *   d_obs_features: NULL or (B,O) receiving d loss / d obs_features (needs grads), as in vita_compute_loss_f32.
  * use_imf = 1 is improved MeanFlow (flow_matcher.name = "improved_mean", :137-163).
  */
 typedef struct vita_meanflow_policy_weights {
@@ -501,8 +505,9 @@ enum { VITA_MF_LOSS_TOTAL = 0, VITA_MF_LOSS_FLOW = 1 /* meanflow_loss, or imf_lo
 size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_weights* w, const vita_meanflow_loss_config* cfg, int32_t B);
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
-                                   const float* t, const float* r, const float* enc_noise, int32_t B, float* losses, void* workspace,
-                                   size_t workspace_bytes, vita_stream_t stream);
+                                   const float* t, const float* r, const float* enc_noise, int32_t B, float* losses,
+                                   float* d_obs_features, int64_t ld_dobs, void* workspace, size_t workspace_bytes,
+                                   vita_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -24,7 +24,7 @@ def test_library_loads_and_exports_every_symbol():
     lib = _lib.load()
     for name in header_functions():
         assert hasattr(lib, name), name
-    assert lib.vita_abi_version() == 1
+    assert lib.vita_abi_version() == 2
     assert lib.vita_loss_partials_count() == 1024
 
 
@@ -35,12 +35,15 @@ def test_struct_layouts_match_the_header(tmp_path):
     src = tmp_path / "sz.c"
     src.write_text(
         '#include <stdio.h>\n#include <stddef.h>\n#include "vita_hip.h"\n'
-        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vita_linear_args), '
+        'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(vita_linear_args), '
         'sizeof(vita_flownet_weights), sizeof(vita_decoder_weights), offsetof(vita_linear_args, resid), '
         'offsetof(vita_linear_args, gate_scalar), offsetof(vita_flownet_weights, out_b), '
         'offsetof(vita_decoder_weights, out_w), sizeof(vita_encoder_weights), sizeof(vita_policy_weights), '
         'sizeof(vita_loss_config), offsetof(vita_policy_weights, dec), offsetof(vita_encoder_weights, proj_w), '
-        'offsetof(vita_linear_args, act_grad_z), sizeof(vita_meanflow_weights), offsetof(vita_meanflow_weights, u_w)); return 0;}\n')
+        'offsetof(vita_linear_args, act_grad_z), sizeof(vita_meanflow_weights), offsetof(vita_meanflow_weights, u_w), '
+        'sizeof(vita_meanflow_loss_config), offsetof(vita_meanflow_loss_config, kl_weight), offsetof(vita_meanflow_loss_config, use_imf), '
+        'sizeof(vita_meanflow_policy_weights), offsetof(vita_meanflow_policy_weights, dec), sizeof(vita_bf16_weights), '
+        'offsetof(vita_bf16_weights, dec_fc2_w), offsetof(vita_loss_config, side_streams)); return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
@@ -49,7 +52,10 @@ def test_struct_layouts_match_the_header(tmp_path):
             _lib.LinearArgs.resid.offset, _lib.LinearArgs.gate_scalar.offset, _lib.FlowNetWeights.out_b.offset,
             _lib.DecoderWeights.out_w.offset, ctypes.sizeof(_lib.EncoderWeights), ctypes.sizeof(_lib.PolicyWeights),
             ctypes.sizeof(_lib.LossConfig), _lib.PolicyWeights.dec.offset, _lib.EncoderWeights.proj_w.offset,
-            _lib.LinearArgs.act_grad_z.offset, ctypes.sizeof(_lib.MeanFlowWeights), _lib.MeanFlowWeights.u_w.offset]
+            _lib.LinearArgs.act_grad_z.offset, ctypes.sizeof(_lib.MeanFlowWeights), _lib.MeanFlowWeights.u_w.offset,
+            ctypes.sizeof(_lib.MeanFlowLossConfig), _lib.MeanFlowLossConfig.kl_weight.offset, _lib.MeanFlowLossConfig.use_imf.offset,
+            ctypes.sizeof(_lib.MeanFlowPolicyWeights), _lib.MeanFlowPolicyWeights.dec.offset, ctypes.sizeof(_lib.Bf16Weights),
+            _lib.Bf16Weights.dec_fc2_w.offset, _lib.LossConfig.side_streams.offset]
     assert got == want
 
 

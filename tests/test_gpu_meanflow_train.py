@@ -150,14 +150,106 @@ def test_meanflow_step_vs_oracle_fp64(ops, dev, variant):
     if variant.startswith("imf"):
         for k, i in (("imf_loss", 5), ("aux_v_loss", 6), ("imf_mse", 7), ("aux_v_mse", 8)):
             assert abs(losses[i].item() - m[k].item()) <= 1e-5 * abs(m[k].item()), k
+    bad = []
     for k, gr in zip(keys, gs):
         if gr is None or gr.abs().max().item() == 0:
             assert grads[k].abs().max().item() == 0, f"{variant}: grad {k} should be zero"
+        elif nerr(grads[k], gr) > 2e-5:
+            bad.append(k)
+    if bad:
+        # The only admissible cause: a ReLU kink.  A conv pre-activation that is ~1e-8 in fp64 can come out with the other sign in
+        # fp32 (on the CPU too), and then the fp32 path masks that element differently from the fp64 oracle: not an arithmetic
+        # error, but it moves the gradients upstream of it by far more than 2e-5.  Make the comparison mask-consistent instead of
+        # loosening it: the borderline pre-activations (sign differs in an fp32 evaluation, |z| < 1e-6 in fp64) must be at most three, only encoder-conv gradients may
+        # be affected, and under ONE assignment of those elements' signs the fp64 oracle must match every gradient to 2e-5.
+        import itertools
+        assert all(k.startswith("action_encoder.encoder.") for k in bad), f"{variant}: {bad}"
+        O.CNN_PREACT_TRACE = []
+        try:
+            with torch.no_grad():
+                O.cnn_action_encode({k: v.detach() for k, v in sd64.items()}, actions.double())
+            zs = O.CNN_PREACT_TRACE
+        finally:
+            O.CNN_PREACT_TRACE = None
+        O.CNN_PREACT_TRACE = []
+        try:
+            with torch.no_grad():
+                O.cnn_action_encode({k: v.detach().float() for k, v in sd64.items()}, actions.float())
+            zs32 = O.CNN_PREACT_TRACE
+        finally:
+            O.CNN_PREACT_TRACE = None
+        # candidates: where an fp32 evaluation (CPU) already lands on the other side of 0, or |z| is below fp32's resolution of
+        # these sums; every candidate must be tiny in fp64
+        border = [(2 * li, idx) for li, (z, z32) in enumerate(zip(zs, zs32))
+                  for idx in (((z > 0) != (z32 > 0)) | (z.abs() < 1e-7)).nonzero().tolist()]
+        assert 1 <= len(border) <= 3, f"{variant}: {len(border)} borderline conv pre-activations, gradients off: {bad}"
+        assert all(zs[layer // 2][tuple(idx)].abs().item() < 1e-6 for layer, idx in border), f"{variant}: {border}"
+        matched = False
+        for signs in itertools.product((False, True), repeat=len(border)):
+            masks = {2 * li: (z > 0) for li, z in enumerate(zs)}
+            for (layer, idx), sg in zip(border, signs):
+                masks[layer][tuple(idx)] = sg
+            O.CNN_RELU_MASK = masks
+            try:
+                loss_m, _ = O.compute_loss_meanflow(sd64, obs.double(), actions.double(), t.double(), r.double(), K, **kw)
+                gm = torch.autograd.grad(loss_m, [sd64[k] for k in keys], allow_unused=True)
+            finally:
+                O.CNN_RELU_MASK = None
+            if all(g_ is None or g_.abs().max().item() == 0 or nerr(grads[k], g_) <= 2e-5 for k, g_ in zip(keys, gm)):
+                matched = True
+                break
+        assert matched, f"{variant}: no sign assignment of the {len(border)} borderline pre-activation(s) explains gradients {bad}"
+
+
+def test_meanflow_step_d_obs_features(ops, dev):
+    """d loss / d obs_features of the MeanFlow step (what a trainable observer receives, vita_policy.py:113-114) against the fp64
+    oracle's autograd; mean and improved_mean."""
+    g = torch.Generator().manual_seed(77)
+    A, T, B, D, H, Lh, O_ = 7, 16, 19, 64, 64, 3, 40
+    base = O.make_state_dict(O_, A, latent_dim=D, hidden_dim=64, num_layers=1, pred_horizon=T, ae_hidden=48, ae_layers=4, time_embed_dim=16, seed=51)
+    sd = {k: v for k, v in base.items() if not k.startswith("flow_net.")}
+    sd.update(O.make_meanflow_state_dict(D, H, Lh, 4.0, seed=52))
+    obs, actions = torch.randn(B, O_, generator=g), torch.randn(B, T, A, generator=g)
+    smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
+    t, r = smp.max(1)[0], smp.min(1)[0]
+    for use_imf in (False, True):
+        o64 = obs.double().requires_grad_(True)
+        loss, _ = O.compute_loss_meanflow({k: v.double() for k, v in sd.items()}, o64, actions.double(), t.double(), r.double(), 2, use_imf=use_imf)
+        want, = torch.autograd.grad(loss, [o64])
+        sdd = {k: v.to(dev).contiguous() for k, v in sd.items()}
+        gsd = {k: torch.zeros_like(v) for k, v in sdd.items()}
+        pw = ops.MeanFlowPolicyHandle(sdd, dev, pred_horizon=T, strict=True)
+        gw = ops.MeanFlowPolicyHandle(gsd, dev, pred_horizon=T, strict=True)
+        losses, dobs = ops.compute_loss_meanflow(pw, ops.meanflow_loss_config(num_steps=2, use_imf=use_imf), obs.to(dev), actions.to(dev), t.to(dev),
+                                                 r.to(dev), grads=gw, need_dobs=True)
+        assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item())
+        assert nerr(dobs, want) <= 2e-5, (use_imf, nerr(dobs, want))
+
+
+def test_meanflow_variational_colsum_wider_than_ff_large_batch(ops, dev):
+    """B > 2048 takes the two-stage column sums; with the variational encoder the widest one is latent_proj's (B, 2D) bias
+    gradient, wider than FF / 4C here: the partials scratch must be sized for it (it overran into the next buffers before)."""
+    g = torch.Generator().manual_seed(78)
+    A, T, B, D, H, Lh, O_ = 3, 16, 2176, 64, 16, 2, 24
+    base = O.make_state_dict(O_, A, latent_dim=D, hidden_dim=16, num_layers=1, pred_horizon=T, ae_hidden=16, ae_layers=4, time_embed_dim=16, seed=61,
+                             variational=True)
+    sd = {k: v for k, v in base.items() if not k.startswith("flow_net.")}
+    sd.update(O.make_meanflow_state_dict(D, H, Lh, 4.0, seed=62))
+    obs, actions = torch.randn(B, O_, generator=g), torch.randn(B, T, A, generator=g)
+    smp = torch.sigmoid(torch.randn(B, 2, generator=g) - 0.4)
+    t, r = smp.max(1)[0], smp.min(1)[0]
+    noise = torch.randn(B, D, generator=g)
+    sd64 = {k: v.double().requires_grad_(True) for k, v in sd.items()}
+    loss, _ = O.compute_loss_meanflow(sd64, obs.double(), actions.double(), t.double(), r.double(), 1, kl_weight=0.01, enc_noise=noise.double())
+    keys = list(sd64)
+    gs = torch.autograd.grad(loss, [sd64[k] for k in keys], allow_unused=True)
+    losses, grads = run(ops, dev, sd, obs, actions, t, r, ops.meanflow_loss_config(num_steps=1, kl_weight=0.01), enc_noise=noise)
+    assert abs(losses[0].item() - loss.item()) <= 1e-5 * abs(loss.item())
+    for k, gr in zip(keys, gs):
+        if gr is None or gr.abs().max().item() == 0:
+            assert grads[k].abs().max().item() == 0, k
         else:
-            # B = 640: one of the 1.3 M pre-activations of the second conv is 1.8e-8 in fp64 and changes sign in fp32 (on the CPU
-            # too), so its ReLU mask differs from the fp64 oracle's and the gradients upstream of it carry that one element
-            tol = 1e-2 if (variant.endswith("b640") and k.startswith("action_encoder.encoder.")) else 2e-5
-            assert nerr(grads[k], gr) <= tol, f"{variant}: grad {k} {nerr(grads[k], gr):g}"
+            assert nerr(grads[k], gr) <= 5e-5, f"grad {k} {nerr(grads[k], gr):g}"
 
 
 def test_policy_mean_matcher_trains(dev):
@@ -267,7 +359,7 @@ def test_policy_mean_matcher_freeze_encoder(dev):
     loss.backward()
     for k, p in pol.hot_path_named_parameters():
         if k.startswith("action_encoder."):
-            assert p.grad is None or p.grad.abs().max().item() == 0, k
+            assert p.grad is None, k      # frozen modules keep .grad = None, as in the reference
     assert pol.action_decoder.output_proj.weight.grad.abs().max().item() > 0 if hasattr(pol.action_decoder, "output_proj") else True
 
 

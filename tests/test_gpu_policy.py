@@ -208,6 +208,89 @@ def test_trainer_steps_match_the_reference_step_restated_on_cpu(tmp_path):
     assert set(sd1) == set(sd2) and all(torch.equal(sd1[k], sd2[k]) for k in sd1)
 
 
+def test_training_state_is_the_reference_schema(tmp_path):
+    """training_state.pt as policy_trainer.py:268-274 writes it: torch's own AdamW / LambdaLR load it, the EMA entry has
+    diffusers' EMAModel keys; and a file written by the REFERENCE, whose parameter list also holds the ResNet observer's
+    tensors between the Normalize statistics and obs_encoder (vita_policy.py:43-50,77), resumes here (aligned from the end)."""
+    cfg = small_cfg()
+    pol = make_policy(cfg)
+    tr = PolicyTrainer(cfg, pol, DEV, num_training_steps=100)
+    g = torch.Generator().manual_seed(6)
+    batch = make_batch(cfg, 16, g)
+    for _ in range(2):
+        tr.train_step({k: v.clone() for k, v in batch.items()}, t=torch.rand(16, generator=g).to(DEV))
+    tr.save_checkpoint(str(tmp_path))
+    st = torch.load(str(tmp_path / "training_state.pt"), weights_only=True)
+    assert set(st) == {"optimizer", "lr_scheduler", "ema", "step"} and st["step"] == 2
+    # the reference's own loaders (policy_trainer.py:299-305): torch.optim.AdamW / LambdaLR .load_state_dict
+    opt = pol.get_optimizer()
+    opt.load_state_dict(st["optimizer"])
+    sch = pol.get_scheduler(opt, 100)
+    sch.load_state_dict(st["lr_scheduler"])
+    assert sch.last_epoch == 2 and abs(opt.param_groups[0]["lr"] - tr.current_lr()) < 1e-12
+    params = list(pol.parameters())
+    n_norm = sum(1 for p in params if not p.requires_grad)
+    assert len(st["optimizer"]["param_groups"][0]["params"]) == len(params)
+    assert sorted(st["optimizer"]["state"]) == list(range(n_norm, len(params)))       # frozen statistics carry no state
+    off = {id(p): o for o, p in zip(__import__("itertools").accumulate([0] + [q.numel() for _, q in pol.hot_path_named_parameters()]),
+                                    [q for _, q in pol.hot_path_named_parameters()])}
+    for i, p in enumerate(params):
+        if p.requires_grad:
+            ent = opt.state[p]
+            assert float(ent["step"]) == 2.0 and ent["exp_avg"].shape == p.shape
+            assert torch.equal(ent["exp_avg"].reshape(-1).cpu(), tr.exp_avg[off[id(p)]:off[id(p)] + p.numel()].cpu())
+    ema = st["ema"]
+    assert {"decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma", "power", "shadow_params"} <= set(ema)
+    assert ema["optimization_step"] == 2 and len(ema["shadow_params"]) == len(params)
+    # a reference-written file: 3 extra (observer) parameters after the Normalize statistics, every index shifted
+    ref_st = {"optimizer": {"state": {}, "param_groups": [dict(st["optimizer"]["param_groups"][0])]}, "lr_scheduler": st["lr_scheduler"],
+              "ema": dict(ema), "step": 2}
+    extra = [torch.randn(4, 3), torch.randn(7), torch.randn(2, 2, 2)]
+    ref_st["optimizer"]["param_groups"][0]["params"] = list(range(len(params) + 3))
+    for i, ent in st["optimizer"]["state"].items():
+        ref_st["optimizer"]["state"][i + 3] = ent
+    for j, e in enumerate(extra):
+        ref_st["optimizer"]["state"][n_norm + j] = {"step": torch.tensor(2.0), "exp_avg": e, "exp_avg_sq": e * e}
+    ref_st["ema"]["shadow_params"] = ema["shadow_params"][:n_norm] + extra + ema["shadow_params"][n_norm:]
+    pol2 = make_policy(cfg, seed=9)
+    tr2 = PolicyTrainer(cfg, pol2, DEV, num_training_steps=100)
+    tr2.load_training_state(ref_st)
+    assert tr2.step_counter == 2 and torch.equal(tr2.exp_avg, tr.exp_avg) and torch.equal(tr2.exp_avg_sq, tr.exp_avg_sq) and torch.equal(tr2.ema, tr.ema)
+    # a file whose moments do not fit is refused before anything is written
+    bad = {"optimizer": {"state": {k: dict(v) for k, v in st["optimizer"]["state"].items()}, "param_groups": st["optimizer"]["param_groups"]},
+           "lr_scheduler": None, "ema": None, "step": 1}
+    first = min(bad["optimizer"]["state"])
+    bad["optimizer"]["state"][first]["exp_avg"] = torch.zeros(3)
+    before = tr2.exp_avg.clone()
+    with pytest.raises(L.VitaHipError):
+        tr2.load_training_state(bad)
+    assert torch.equal(tr2.exp_avg, before) and tr2.step_counter == 2
+
+
+def test_bf16_weight_cache_follows_the_native_optimizer():
+    """The fused optimizer kernel writes the parameters through raw pointers (no torch version bump): generate_actions with
+    gemm_dtype = bf16 after PolicyTrainer.train_step must use bf16 copies of the UPDATED weights."""
+    cfg = small_cfg()
+    cfg.policy.gemm_dtype = "bf16"
+    cfg.optimizer_lr = 5e-2            # a step large enough that stale weights miss the tolerance by far
+    cfg.scheduler_name = "constant"
+    pol = make_policy(cfg)
+    tr = PolicyTrainer(cfg, pol, DEV, num_training_steps=100)
+    g = torch.Generator().manual_seed(8)
+    batch = make_batch(cfg, 16, g)
+    nb = pol.normalize_inputs({k: v.to(DEV) for k, v in batch.items()})
+    pol.eval()
+    a0 = pol.generate_actions(nb).clone()          # packs the bf16 copies of the initial weights
+    for _ in range(3):
+        tr.train_step({k: v.clone() for k, v in batch.items()}, t=torch.rand(16, generator=g).to(DEV))
+    pol.eval()
+    a1 = pol.generate_actions(nb)
+    feats, _ = oracle_features(pol, batch, cfg)
+    ref = O.generate_actions(hot_sd(pol), feats, cfg.policy.flow_matcher.num_sampling_steps, cfg.policy.pred_horizon, cfg.task.action_dim)
+    assert nerr(a0.reshape(ref.shape), ref) > 0.1, "the step did not move the weights enough for this test to mean anything"
+    assert nerr(a1.reshape(ref.shape), ref) <= 2e-2
+
+
 def test_freeze_flags_and_contrastive_terms_at_policy_level():
     """action_ae.freeze_encoder (vita_policy.py:119,153) with the contrastive weights on: metric keys as the reference emits
     them, frozen module without gradient under the autograd bridge, and untouched bit-for-bit by the native trainer."""

@@ -209,3 +209,26 @@ def test_oracle_matcher_paths_are_consistent():
     assert torch.allclose(ut, x1 - x0, atol=1e-12) and torch.allclose(xt, 0.5 * (x0 + x1) + 0.35 * eps, atol=1e-12)
     _, xt, _ = O.cfm_sample_location_and_conditional_flow(x0, x1, t, 0.3, eps, "conditional")
     assert torch.allclose(xt, t[:, None] * x1 + (1 - t[:, None]) * x0 + 0.3 * eps, atol=1e-12)
+
+
+def test_bench_self_launches_one_process_per_gpu():
+    """`python bench.py --gpus N` without a launcher (the driver's command form) starts N rank processes itself with the
+    torch.distributed.run environment; --dry-launch makes each print that environment and exit before touching a GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-launch"], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr
+    lines = [json.loads(ln) for ln in (r.stdout + r.stderr).splitlines() if ln.startswith("{")]
+    assert sorted(d["rank"] for d in lines) == [0, 1, 2, 3] and all(d["local_rank"] == d["rank"] and d["world"] == 4 for d in lines)
+    assert len({d["pid"] for d in lines}) == 4 and len({d["ppid"] for d in lines}) == 1
+    assert len({d["master_port"] for d in lines}) == 1 and all(d["master_addr"] == "127.0.0.1" for d in lines)
+    assert [json.loads(ln)["rank"] for ln in r.stdout.splitlines() if ln.startswith("{")] == [0]      # only rank 0 on stdout
+    # under a launcher (WORLD_SIZE set) nothing is spawned, and a mismatch with --gpus is an error
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="3", RANK="0"),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr

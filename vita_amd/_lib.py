@@ -154,6 +154,7 @@ SIGNATURES = {
     "vita_last_error": (C.c_char_p, []),
     "vita_linear_f32": (C.c_int, [C.POINTER(LinearArgs), c_fp]),
     "vita_splitk_workspace_bytes": (C.c_size_t, []),
+    "vita_debug_last_gemm_config": (C.c_char_p, []),
     "vita_flownet_forward_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.c_int32]),
     "vita_flownet_forward_f32": (C.c_int, [C.POINTER(FlowNetWeights), c_fp, C.c_int64, c_fp, c_fp, C.c_int64,
                                            C.c_int32, c_fp, C.c_size_t, c_fp]),
@@ -222,8 +223,8 @@ SIGNATURES = {
                                            C.c_size_t, c_fp]),
     "vita_compute_loss_meanflow_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowLossConfig), C.c_int32]),
     "vita_compute_loss_meanflow_f32": (C.c_int, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowPolicyWeights),
-                                                 C.POINTER(MeanFlowLossConfig), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp, c_fp,
-                                                 C.c_size_t, c_fp]),
+                                                 C.POINTER(MeanFlowLossConfig), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp,
+                                                 c_fp, C.c_int64, c_fp, C.c_size_t, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,

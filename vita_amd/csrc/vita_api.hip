@@ -19,6 +19,15 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// Size of the split-K region at the head of every carve below: kSplitkBytes for the workspace-taking entry points, smaller
+// inside the allocation-free entry point (vita_generate_actions_noalloc_f32), whose whole scratch is a fixed array.
+static thread_local size_t tl_skb = kSplitkBytes;
+struct SkbScope {
+    size_t saved;
+    explicit SkbScope(size_t n) : saved(tl_skb) { tl_skb = n; }
+    ~SkbScope() { tl_skb = saved; }
+};
+
 struct FlowWs {
     float *sk, *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
     float *stat, *c1, *c2, *c1f, *c2f;   // folded LayerNorm (sampling at large batch): row statistics and the c-tables
@@ -38,7 +47,7 @@ static bool use_ln_fold(const vita_flownet_weights* w, int B) {
 static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, bool need_x) {
     Carver c(ws);
     FlowWs f;
-    f.sk = c.take(kSplitkBytes / sizeof(float));
+    f.sk = c.take(tl_skb / sizeof(float));
     f.ts = c.take((size_t)T);
     f.sin = c.take((size_t)T * w->TE);
     f.hid = c.take((size_t)T * 4 * w->TE);
@@ -163,7 +172,7 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
                       float* traj, void* ws, hipStream_t s) {
     const int D = w->D, H = w->H, L = w->L;
     FlowWs f = carve_flow(ws, w, B, K, false);
-    SplitkScope sk(f.sk, kSplitkBytes);
+    SplitkScope sk(f.sk, tl_skb);
     VITA_TRY(launch_step_times(f.ts, K, s));
     VITA_TRY(time_path(w, f, K, s));
     const bool fold = f.stat != nullptr;
@@ -222,7 +231,7 @@ struct DecWs { float *sk, *a, *b; size_t bytes; };
 static DecWs carve_dec(void* ws, const vita_decoder_weights* w, int B) {
     Carver c(ws);
     DecWs d;
-    d.sk = c.take(kSplitkBytes / sizeof(float));
+    d.sk = c.take(tl_skb / sizeof(float));
     d.a = c.take((size_t)B * w->HD);
     d.b = c.take((size_t)B * w->HD);
     d.bytes = c.off;
@@ -240,7 +249,7 @@ static int decoder_forward(const vita_decoder_weights* w, const float* z, int64_
                            hipStream_t s) {
     const int D = w->D, HD = w->HD;
     DecWs d = carve_dec(ws, w, B);
-    SplitkScope sk(d.sk, kSplitkBytes);
+    SplitkScope sk(d.sk, tl_skb);
     VITA_TRY(gemm_f32(lin(z, ldz, w->in_w, D, w->in_b, d.a, HD, B, HD, D, VITA_ACT_NONE), s));           // action_ae.py:274
     for (int i = 0; i < w->NL; ++i) {                                                                     // :275-276
         VITA_TRY(gemm_f32(lin(d.a, HD, w->fc1_w[i], HD, w->fc1_b[i], d.b, HD, B, HD, HD, VITA_ACT_GELU_ERF), s));
@@ -260,6 +269,7 @@ int vita_abi_version(void) { return VITA_ABI_VERSION; }
 const char* vita_last_error(void) { return g_err; }
 
 size_t vita_splitk_workspace_bytes(void) { return size_t(32) << 20; }
+const char* vita_debug_last_gemm_config(void) { return last_dma_config(); }
 
 int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream) {
     VITA_REQUIRE(args != nullptr, "vita_linear_f32: null args");
@@ -346,30 +356,45 @@ size_t vita_generate_actions_workspace_bytes(const vita_flownet_weights* fw, con
     return lat + (a > b ? a : b);
 }
 
-int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O, const vita_flownet_weights* fw,
-                              const vita_decoder_weights* dw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
-                              float* latents_out, int32_t B, int32_t num_steps, void* workspace, size_t workspace_bytes,
-                              vita_stream_t stream) {
-    VITA_TRY(check_flow_weights(fw, "vita_generate_actions_f32"));
-    VITA_TRY(check_dec_weights(dw, "vita_generate_actions_f32"));
-    VITA_REQUIRE(fw->D == dw->D, "vita_generate_actions_f32: flow-net D=%d != decoder D=%d", fw->D, dw->D);
-    VITA_REQUIRE(num_steps >= 1, "vita_generate_actions_f32: num_steps must be >= 1 (got %d)", num_steps);
-    VITA_REQUIRE(B >= 0 && O > 0, "vita_generate_actions_f32: bad B/O");
+static int generate_actions_checked(const char* who, const float* obs_w, const float* obs_b, int32_t O, const vita_flownet_weights* fw,
+                                    const vita_decoder_weights* dw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                                    int32_t B, int32_t num_steps) {
+    VITA_TRY(check_flow_weights(fw, who));
+    VITA_TRY(check_dec_weights(dw, who));
+    VITA_REQUIRE(fw->D == dw->D, "%s: flow-net D=%d != decoder D=%d", who, fw->D, dw->D);
+    VITA_REQUIRE(num_steps >= 1, "%s: num_steps must be >= 1 (got %d)", who, num_steps);
+    VITA_REQUIRE(B >= 0 && O > 0, "%s: bad B/O", who);
     if (B == 0) return VITA_OK;
-    VITA_REQUIRE(obs_w && obs_b && obs_features && actions && ldobs >= O && lda >= dw->OUT, "vita_generate_actions_f32: bad pointers/strides");
-    VITA_TRY(check_ws(workspace, workspace_bytes, vita_generate_actions_workspace_bytes(fw, dw, B, num_steps), "vita_generate_actions_f32"));
-    hipStream_t s = (hipStream_t)stream;
+    VITA_REQUIRE(obs_w && obs_b && obs_features && actions && ldobs >= O && lda >= dw->OUT, "%s: bad pointers/strides", who);
+    return VITA_OK;
+}
+
+// obs_encoder -> Euler sampler -> decoder on `workspace`, whose carves start with a split-K region of tl_skb bytes
+static int generate_actions_run(const float* obs_w, const float* obs_b, int32_t O, const vita_flownet_weights* fw,
+                                const vita_decoder_weights* dw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                                float* latents_out, int32_t B, int32_t num_steps, void* workspace, hipStream_t s) {
     const int D = fw->D;
     float* lat = static_cast<float*>(workspace);
     char* rest = static_cast<char*>(workspace) + (((size_t)B * D * 4 + 255) & ~size_t(255));
     {
-        SplitkScope sk(rest, kSplitkBytes);   // the first kSplitkBytes of either carve below
+        SplitkScope sk(rest, tl_skb);   // the first tl_skb bytes of either carve below
         VITA_TRY(gemm_f32(lin(obs_features, ldobs, obs_w, O, obs_b, lat, D, B, D, O, VITA_ACT_NONE), s));  // vita_policy.py:194
     }
     VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s));                           // :196-203
     if (latents_out)
         VITA_CHECK_HIP(hipMemcpyAsync(latents_out, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s));
     return decoder_forward(dw, lat, D, actions, lda, B, rest, s);                                       // :206
+}
+
+int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O, const vita_flownet_weights* fw,
+                              const vita_decoder_weights* dw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                              float* latents_out, int32_t B, int32_t num_steps, void* workspace, size_t workspace_bytes,
+                              vita_stream_t stream) {
+    VITA_TRY(generate_actions_checked("vita_generate_actions_f32", obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, B, num_steps));
+    if (B == 0) return VITA_OK;
+    VITA_TRY(check_ws(workspace, workspace_bytes, vita_generate_actions_workspace_bytes(fw, dw, B, num_steps), "vita_generate_actions_f32"));
+    return generate_actions_run(obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, latents_out, B, num_steps, workspace,
+                                (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -22,6 +22,7 @@
 //                 so it is applied to the A fragments after the LDS read: (a-mean)*rstd from
 //                 per-lane row statistics, then *mul[k] + add[k] from LDS tables — VALU work
 //                 that hides under the 64-cycle fp32 MFMAs.
+#include <stdio.h>
 #include <type_traits>
 
 #include "vita_common.h"
@@ -405,9 +406,14 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
     RSTAMP(5);
 }
 
+// what the last LDS-DMA launch of this host thread dispatched (bench.py labels its roofline kernel from it)
+static thread_local char g_last_cfg[96] = "";
+const char* last_dma_config() { return g_last_cfg; }
+
 template <int BM, int BN, int BK, int NS>
 static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
     GemmParamsDma p = p0;
+    snprintf(g_last_cfg, sizeof(g_last_cfg), "gemm_f32_dma_kernel<%d,%d,%d,%d,bf16>", BM, BN, BK, NS);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
     const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
@@ -440,6 +446,8 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
 #endif
     }
     const bool ln = p.pro != VITA_PRO_NONE;
+    snprintf(g_last_cfg, sizeof(g_last_cfg), "gemm_f32_dma_kernel<%d,%d,%d,%d,KG=%d%s> xcd %dx%d", BM, BN, BK, NS, KG, ln ? ",LN" : "",
+             p.xcd_nbr, p.xcd_nbc);
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0) + (p.epi.ln_stats ? 2 * BM : 0)) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(DNT);
     if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC, false, KG>), grid, block, lds, stream, p);

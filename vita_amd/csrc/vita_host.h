@@ -6,6 +6,7 @@
 namespace vita {
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream);
+const char* last_dma_config();   // "<BM,BN,BK,NS,KG>" of the calling thread's last LDS-DMA launch ("" = none yet)
 // LayerNorm folded into the neighbouring GEMMs' epilogues (see EpiParams in vita_gemm_epilogue.h).  Producer fields:
 // aux_out/aux_mul/stat_out; consumer fields: ln_stats/ln_c1.  Requires the LDS-DMA kernel, M % 256 == 0, N % 128 == 0 and
 // 16-byte aligned operands (every tile interior); returns an error otherwise.

@@ -1121,7 +1121,8 @@ struct MfTrainWs {
 int max_colsum_n_mf(const vita_meanflow_policy_weights& w) {
     int n = w.flow.FF;
     auto up = [&](int v) { if (v > n) n = v; };
-    up(w.flow.H); up(w.flow.D); up(w.dec.HD); up(w.dec.OUT); up(w.dec.D); up(w.enc.C * 4); up(w.enc.D);
+    up(w.flow.H); up(w.flow.D); up(w.dec.HD); up(w.dec.OUT); up(w.dec.D); up(w.enc.C * 4);
+    up(w.enc.D * (w.enc.variational ? 2 : 1));   // the variational latent_proj's bias gradient is a (B, 2D) column sum
     return n;
 }
 MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const vita_meanflow_loss_config& cfg, size_t B) {
@@ -1263,9 +1264,11 @@ size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_wei
 
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
-                                   const float* t, const float* r, const float* enc_noise, int32_t B, float* losses, void* workspace,
-                                   size_t workspace_bytes, vita_stream_t stream) {
+                                   const float* t, const float* r, const float* enc_noise, int32_t B, float* losses,
+                                   float* d_obs_features, int64_t ld_dobs, void* workspace, size_t workspace_bytes,
+                                   vita_stream_t stream) {
     const char* who = "vita_compute_loss_meanflow_f32";
+    VITA_REQUIRE(d_obs_features == nullptr || (grads != nullptr && w != nullptr && ld_dobs >= w->O), "%s: d_obs_features needs grads and ld_dobs >= O", who);
     VITA_REQUIRE(w && cfg, "%s: null weights / config", who);
     VITA_REQUIRE(w->O > 0 && w->obs_w && w->obs_b, "%s: bad obs_encoder", who);
     VITA_TRY(check_mfw(&w->flow, who));
@@ -1565,6 +1568,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     }
     VITA_TRY(gemm_f32(wgrad(s.dz0, D, obs_features, ldobs, mut(g.obs_w), w->O, B, w->O, D), st));
     VITA_TRY(vita_colsum_f32(s.dz0, D, B, D, s.cs_part, mut(g.obs_b), 0, st));
+    // what flows on into a trainable observer (vita_policy.py:113-114): d obs_features = d z0 . obs_w
+    if (d_obs_features) VITA_TRY(gemm_f32(dgrad(s.dz0, D, w->obs_w, w->O, d_obs_features, ld_dobs, B, w->O, D), st));
     return VITA_OK;
 }
 

@@ -944,9 +944,10 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
 
 def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, r: Tensor, *,
                           grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None,
-                          enc_noise: Optional[Tensor] = None) -> Tensor:
+                          enc_noise: Optional[Tensor] = None, need_dobs: bool = False):
     """VitaPolicy.compute_loss with the MeanFlow matcher (+ backward when `grads` is given): vita_compute_loss_meanflow_f32.
-    Returns losses (16,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss).  No host sync."""
+    Returns losses (16,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss); with need_dobs
+    (and grads) the pair (losses, d loss / d obs_features).  No host sync."""
     lib = L.load()
     obs_features = _rows(obs_features, "compute_loss_meanflow: obs_features")
     actions = _f32(actions, "compute_loss_meanflow: actions").contiguous()
@@ -969,11 +970,16 @@ def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, a
         raise L.VitaHipError(f"compute_loss_meanflow: losses needs {L.MF_LOSS_COUNT} floats")
     nbytes = lib.vita_compute_loss_meanflow_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
     ws = workspace(dev, nbytes)
+    if need_dobs and grads is None:
+        raise L.VitaHipError("compute_loss_meanflow: need_dobs needs grads")
+    dobs = torch.empty_like(obs_features) if need_dobs else None
     L.check(lib.vita_compute_loss_meanflow_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
                                                obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(), r.data_ptr(),
-                                               enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(), ws.data_ptr(), ws.numel(), _stream(obs_features)),
+                                               enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
+                                               dobs.data_ptr() if dobs is not None else None, _ld(dobs) if dobs is not None else 0,
+                                               ws.data_ptr(), ws.numel(), _stream(obs_features)),
             "vita_compute_loss_meanflow_f32")
-    return losses
+    return (losses, dobs) if need_dobs else losses
 
 
 def action_encoder_forward(pw: PolicyHandle, actions: Tensor) -> Tensor:

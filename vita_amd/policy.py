@@ -211,15 +211,15 @@ class _FusedLoss(torch.autograd.Function):
         need_dobs = obs_features.requires_grad
         losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
                                         need_dobs=need_dobs, enc_noise=enc_noise, fm_noise=fm_noise)
-        ctx.staged, ctx.dobs = staged, dobs
+        ctx.staged, ctx.dobs, ctx.buf = staged, dobs, policy._cache["stage_buf"]
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
 
     @staticmethod
     def backward(ctx, gout, _):
-        grads = tuple((g * gout if g is not None else None) for g in ctx.staged)
+        ctx.buf.mul_(gout)      # ONE pass over the flat staging buffer (the incoming grad is a device scalar: no host check)
         dobs = ctx.dobs * gout if ctx.dobs is not None else None
-        return (None, dobs, None, None, None, None, None, None) + grads
+        return (None, dobs, None, None, None, None, None, None) + tuple(ctx.staged)
 
 
 class _FusedMeanFlowLoss(torch.autograd.Function):
@@ -228,14 +228,23 @@ class _FusedMeanFlowLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, policy, obs_features, actions, t, r, enc_noise, *params):
         pw, gw, gsd = policy._train_handles(stage=True)
-        losses = ops.compute_loss_meanflow(pw, policy._mf_cfg, obs_features.detach(), actions, t, r, grads=gw, enc_noise=enc_noise)
-        ctx.staged = [gsd[k] for k, _ in policy.hot_path_named_parameters()]
+        ctx.dobs = None
+        if obs_features.requires_grad:      # a trainable observer upstream (vita_policy.py:113-114)
+            losses, ctx.dobs = ops.compute_loss_meanflow(pw, policy._mf_cfg, obs_features.detach(), actions, t, r, grads=gw,
+                                                         enc_noise=enc_noise, need_dobs=True)
+        else:
+            losses = ops.compute_loss_meanflow(pw, policy._mf_cfg, obs_features.detach(), actions, t, r, grads=gw, enc_noise=enc_noise)
+        frozen = policy.frozen_prefixes()     # frozen modules keep .grad = None, as in the reference (and as _FusedLoss does)
+        ctx.staged = [None if k.startswith(frozen) else gsd[k] for k, _ in policy.hot_path_named_parameters()]
+        ctx.buf = policy._cache["stage_buf"]
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
 
     @staticmethod
     def backward(ctx, gout, _):
-        return (None, None, None, None, None, None) + tuple(g * gout for g in ctx.staged)
+        ctx.buf.mul_(gout)
+        dobs = ctx.dobs * gout if ctx.dobs is not None else None
+        return (None, dobs, None, None, None, None) + tuple(ctx.staged)
 
 
 class VitaPolicy(nn.Module):
@@ -335,8 +344,14 @@ class VitaPolicy(nn.Module):
                                                     kl_weight=float(self.action_kl_weight) if self.use_action_vae else 0.0)
         self._flat = self._flat_grad = None
         self._cache = {}
+        self._weights_epoch = 0
         self.bucket_ranges = None
         self.reset()
+
+    def mark_weights_updated(self):
+        """Tell the policy that parameter VALUES changed behind torch's back (the fused optimizer kernel and checkpoint loads
+        write through raw pointers, which bumps no tensor version): derived copies (the packed bf16 weights) are rebuilt."""
+        self._weights_epoch += 1
 
     # -- parameter plumbing --------------------------------------------------------------------------
     def hot_path_named_parameters(self):
@@ -430,6 +445,7 @@ class VitaPolicy(nn.Module):
             if stage:
                 n = sum(p.numel() for _, p in named)
                 buf = torch.zeros(n, dtype=torch.float32, device=named[0][1].device)
+                self._cache["stage_buf"] = buf
                 gsd, off = {}, 0
                 for k, p in named:
                     gsd[k] = buf[off:off + p.numel()].view_as(p)
@@ -628,7 +644,7 @@ class VitaPolicy(nn.Module):
     def _bf16_weights(self):
         """bf16 copies of the GEMM weights, re-packed whenever a parameter has been written since the last pack."""
         named = self.hot_path_named_parameters()
-        version = (self._key(), tuple(p._version for _, p in named))
+        version = (self._key(), self._weights_epoch, tuple(p._version for _, p in named))
         c = self._cache.get("bf16")
         if c is None or c[0] != version:
             c = (version, ops.Bf16Weights({k: p.data for k, p in named}, self.obs_encoder.weight.device))

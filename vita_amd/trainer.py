@@ -89,6 +89,7 @@ class PolicyTrainer:
                                gnorm_sq=self.gnorm_sq, max_norm=float(c.train.grad_clip_norm), grad_scale=scale,
                                ema_decay=ema_decay(step) if self.ema is not None else 0.0)
         self.step_counter = step
+        net.mark_weights_updated()      # the fused optimizer wrote the parameters through raw pointers: no torch version bump
         self.update_s = time.perf_counter() - t0
         return self.losses
 
@@ -103,23 +104,120 @@ class PolicyTrainer:
         out["update_s"] = self.update_s
         return out
 
-    # -- checkpoints: the reference's two files (policy_trainer.py:261-274) ------------------------------------
+    # -- checkpoints: the reference's two files, in the reference's schema (policy_trainer.py:261-311) ----------------
+    def _flat_slices(self):
+        """{id(parameter): (offset, numel)} of the hot-path parameters inside the flat buffers."""
+        out, off = {}, 0
+        for _, p in self.network.hot_path_named_parameters():
+            out[id(p)] = (off, p.numel())
+            off += p.numel()
+        return out
+
+    def training_state(self) -> dict:
+        """`training_state.pt` as the reference writes it (policy_trainer.py:268-274): `optimizer` = torch.optim.AdamW
+        .state_dict() over `network.parameters()` in module order (per-parameter step / exp_avg / exp_avg_sq cut from the flat
+        moment buffers; parameters that never got a gradient -- the frozen Normalize statistics, frozen modules -- carry no
+        state, as in torch), `lr_scheduler` = LambdaLR.state_dict(), `ema` = diffusers EMAModel.state_dict() keys
+        (shadow_params over all parameters, optimization_step, decay, power, ...), `step`."""
+        net, step = self.network, self.step_counter
+        params = list(net.parameters())
+        slices = self._flat_slices()
+        trainable = [(a, b) for a, b in self.update_ranges]
+        opt = net.get_optimizer()
+        sch = net.get_scheduler(opt, self.num_training_steps)
+        if step > 0:
+            for p in params:
+                sl = slices.get(id(p))
+                if sl is None or not any(a <= sl[0] < b for a, b in trainable):
+                    continue
+                off, n = sl
+                opt.state[p] = {"step": torch.tensor(float(step)),
+                                "exp_avg": self.exp_avg[off:off + n].view_as(p).detach().clone().cpu(),
+                                "exp_avg_sq": self.exp_avg_sq[off:off + n].view_as(p).detach().clone().cpu()}
+        lr = self.current_lr()
+        for g in opt.param_groups:
+            g["lr"] = lr
+        sch.last_epoch, sch._step_count, sch._last_lr = step, step + 1, [lr]
+        ema = None
+        if self.ema is not None:
+            shadow = []
+            for p in params:
+                sl = slices.get(id(p))
+                shadow.append((self.ema[sl[0]:sl[0] + sl[1]].view_as(p) if sl is not None else p.data).detach().clone().cpu())
+            ema = {"decay": 0.9999, "min_decay": 0.0, "optimization_step": step, "update_after_step": 0, "use_ema_warmup": False,
+                   "inv_gamma": 1.0, "power": float(self.config.ema_power), "shadow_params": shadow}
+        return {"optimizer": opt.state_dict(), "lr_scheduler": sch.state_dict(), "ema": ema, "step": step}
+
     def save_checkpoint(self, directory: str):
         import os
         self.network.save_pretrained(directory)
-        torch.save({"optimizer": {"exp_avg": self.exp_avg.cpu(), "exp_avg_sq": self.exp_avg_sq.cpu()},
-                    "ema": self.ema.cpu() if self.ema is not None else None, "step": self.step_counter},
-                   os.path.join(directory, "training_state.pt"))
+        torch.save(self.training_state(), os.path.join(directory, "training_state.pt"))
+
+    def load_training_state(self, st: dict):
+        """Inverse of training_state(); also takes a file the reference wrote.  Parameter i of the file is parameter i of
+        `network.parameters()`; a file with MORE parameters (the reference's ResNet18 observer sits between the Normalize
+        statistics and obs_encoder, vita_policy.py:43-50,77) is aligned from the end, where the hot-path modules are.  Every
+        moment tensor's shape is checked against its parameter before anything is written."""
+        net = self.network
+        params = list(net.parameters())
+        slices = self._flat_slices()
+        opt_sd = st["optimizer"]
+        if "param_groups" not in opt_sd or "state" not in opt_sd:
+            raise L.VitaHipError("training_state.pt: 'optimizer' is not a torch optimizer state_dict (round-1 native files are not supported)")
+        ids = [i for g in opt_sd["param_groups"] for i in g["params"]]
+        n_file, n_here = len(ids), len(params)
+        if n_file < n_here:
+            raise L.VitaHipError(f"training_state.pt covers {n_file} parameters, this policy has {n_here}")
+        n_head = next((i for i, p in enumerate(params) if id(p) in slices), n_here)   # parameters in front of the hot path
+        def file_index(i):
+            return ids[i] if i < n_head and n_file == n_here else ids[i + (n_file - n_here)]
+        todo = []
+        for i, p in enumerate(params):
+            sl = slices.get(id(p))
+            if sl is None:
+                continue
+            ent = opt_sd["state"].get(file_index(i))
+            if ent is None:
+                continue
+            for key in ("exp_avg", "exp_avg_sq"):
+                if tuple(ent[key].shape) != tuple(p.shape):
+                    raise L.VitaHipError(f"training_state.pt: {key} of parameter {i} has shape {tuple(ent[key].shape)}, expected {tuple(p.shape)}")
+            todo.append((sl, ent))
+        ema_sd = st.get("ema")
+        shadows = None
+        if self.ema is not None and ema_sd:
+            sp = ema_sd["shadow_params"]
+            if len(sp) != n_file:
+                raise L.VitaHipError(f"training_state.pt: ema.shadow_params has {len(sp)} entries, optimizer covers {n_file}")
+            shadows = []
+            for i, p in enumerate(params):
+                sl = slices.get(id(p))
+                if sl is None:
+                    continue
+                t = sp[i if (i < n_head and n_file == n_here) else i + (n_file - n_here)]
+                if tuple(t.shape) != tuple(p.shape):
+                    raise L.VitaHipError(f"training_state.pt: ema shadow {i} has shape {tuple(t.shape)}, expected {tuple(p.shape)}")
+                shadows.append((sl, t))
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for (off, n), ent in todo:
+            self.exp_avg[off:off + n].copy_(ent["exp_avg"].reshape(-1))
+            self.exp_avg_sq[off:off + n].copy_(ent["exp_avg_sq"].reshape(-1))
+        if shadows is not None:
+            for (off, n), t in shadows:
+                self.ema[off:off + n].copy_(t.reshape(-1))
+        self.step_counter = int(st.get("step", 0))
 
     def load_checkpoint(self, directory: str):
+        """policy_trainer.py:276-311.  The file is read with torch.load(weights_only=True): nothing in it is executed.  A
+        reference file that holds non-tensor objects the safe loader refuses (the reference itself loads with
+        weights_only=False) raises here instead of being unpickled."""
         import os
         self.network.load_pretrained(directory)
-        st = torch.load(os.path.join(directory, "training_state.pt"), weights_only=True)
-        self.exp_avg.copy_(st["optimizer"]["exp_avg"])
-        self.exp_avg_sq.copy_(st["optimizer"]["exp_avg_sq"])
-        if self.ema is not None and st["ema"] is not None:
-            self.ema.copy_(st["ema"])
-        self.step_counter = int(st["step"])
+        st = torch.load(os.path.join(directory, "training_state.pt"), map_location="cpu", weights_only=True)
+        self.load_training_state(st)
+        self.network.mark_weights_updated()
+        return self.step_counter
 
     def ema_state_dict(self) -> dict:
         """EMA weights under the reference's state-dict keys (what validate_online evaluates)."""
