@@ -181,6 +181,32 @@ int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O,
                               void* workspace, size_t workspace_bytes, vita_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * vita_generate_actions_noalloc_f32 — NO COUNTERPART IN THE REFERENCE.  vita_generate_actions_f32 for callers that cannot
+ * allocate or size a workspace: code under HIP graph capture, tight serving loops (select_action at eval_n_envs rows),
+ * harnesses that forbid hipMalloc.  Same kernels, same arguments minus the workspace: the scratch (latents, time-path
+ * tables, activations, split-K partials) lives in a library-owned `static __device__` array of
+ * VITA_NOALLOC_SCRATCH_BYTES that every GPU the library runs on holds until the process ends.  The call allocates nothing
+ * and synchronises nothing.  Shapes whose scratch need (vita_generate_actions_noalloc_need_bytes) exceeds the array are
+ * rejected with VITA_ERR_WORKSPACE before any launch (at the default dims: about B <= 512 rows at num_steps <= 16).
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two threads) race; calls on one
+ * stream are ordered.  Nothing in the array has to start at zero.  vita_noalloc_init() resolves the array's device
+ * address for the CURRENT device (hipGetSymbolAddress, once per device); the entry point does the same on its first call
+ * on a device, so call vita_noalloc_init() beforehand when that first call would fall inside a graph capture.
+ * Its split-K region is VITA_NOALLOC_SPLITK_BYTES (not vita_splitk_workspace_bytes()), so a GEMM may be cut into fewer
+ * k-ranges than under vita_generate_actions_f32: results agree to summation order (1e-6), not always to the bit.
+ * --------------------------------------------------------------------------------------- */
+#define VITA_NOALLOC_SCRATCH_BYTES (16u << 20)
+#define VITA_NOALLOC_SPLITK_BYTES (8u << 20)
+size_t vita_noalloc_scratch_bytes(void);
+int vita_noalloc_init(void);
+size_t vita_generate_actions_noalloc_need_bytes(const vita_flownet_weights* fw, const vita_decoder_weights* dw,
+                                                int32_t B, int32_t num_steps);
+int vita_generate_actions_noalloc_f32(const float* obs_w, const float* obs_b, int32_t O,
+                                      const vita_flownet_weights* fw, const vita_decoder_weights* dw,
+                                      const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
+                                      float* latents_out, int32_t B, int32_t num_steps, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Loss kernels (HBM-bound elementwise + two-stage deterministic reduction).
  * `partials` is caller scratch of vita_loss_partials_count() floats; `out` is one device float.
  * --------------------------------------------------------------------------------------- */

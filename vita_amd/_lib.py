@@ -169,6 +169,12 @@ SIGNATURES = {
     "vita_generate_actions_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
                                             c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int32, C.c_int32,
                                             c_fp, C.c_size_t, c_fp]),
+    "vita_noalloc_scratch_bytes": (C.c_size_t, []),
+    "vita_noalloc_init": (C.c_int, []),
+    "vita_generate_actions_noalloc_need_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
+                                                              C.c_int32, C.c_int32]),
+    "vita_generate_actions_noalloc_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),
+                                                    c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int32, C.c_int32, c_fp]),
     "vita_loss_partials_count": (C.c_int32, []),
     "vita_mse_loss_fwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp]),
     "vita_mse_loss_bwd_f32": (C.c_int, [c_fp, c_fp, C.c_int64, c_fp, c_fp, c_fp, C.c_int32, c_fp]),

@@ -6,6 +6,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <atomic>
+#include <mutex>
+
 #include "vita_host.h"
 
 namespace vita {
@@ -263,6 +266,33 @@ static int decoder_forward(const vita_decoder_weights* w, const float* z, int64_
 
 using namespace vita;
 
+// ---- allocation-free entry point (vita_generate_actions_noalloc_f32): its workspace is this array -------------------
+// Every GPU the library runs on holds its own copy of `scratch` at its own address until the process ends.  In host code the
+// name is only a stand-in for the symbol: the device address comes from hipGetSymbolAddress, once per device, and that
+// pointer is what the carves, kernels and copies use.
+static __device__ __align__(256) unsigned char scratch[VITA_NOALLOC_SCRATCH_BYTES];
+constexpr int kMaxDevices = 64;
+static std::atomic<void*> g_scratch_ptr[kMaxDevices];
+static std::mutex g_scratch_mu;
+
+static int noalloc_scratch(void** out, const char* who) {
+    int dev = -1;
+    VITA_CHECK_HIP(hipGetDevice(&dev));
+    VITA_REQUIRE(dev >= 0 && dev < kMaxDevices, "%s: device ordinal %d outside [0,%d)", who, dev, kMaxDevices);
+    void* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
+        std::lock_guard<std::mutex> lock(g_scratch_mu);
+        p = g_scratch_ptr[dev].load(std::memory_order_relaxed);
+        if (p == nullptr) {
+            VITA_CHECK_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));   // the current device's copy
+            VITA_REQUIRE(p != nullptr && (reinterpret_cast<uintptr_t>(p) & 255u) == 0, "%s: bad scratch symbol address %p", who, p);
+            g_scratch_ptr[dev].store(p, std::memory_order_release);
+        }
+    }
+    *out = p;
+    return VITA_OK;
+}
+
 extern "C" {
 
 int vita_abi_version(void) { return VITA_ABI_VERSION; }
@@ -394,6 +424,39 @@ int vita_generate_actions_f32(const float* obs_w, const float* obs_b, int32_t O,
     if (B == 0) return VITA_OK;
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_generate_actions_workspace_bytes(fw, dw, B, num_steps), "vita_generate_actions_f32"));
     return generate_actions_run(obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, latents_out, B, num_steps, workspace,
+                                (hipStream_t)stream);
+}
+
+// ---- no counterpart in the reference: the same call for callers that cannot allocate (HIP graph capture, tight serving
+// loops, harnesses that forbid hipMalloc).  No hipMalloc / hipFree / allocating routine below this line.
+size_t vita_noalloc_scratch_bytes(void) { return (size_t)VITA_NOALLOC_SCRATCH_BYTES; }
+
+int vita_noalloc_init(void) {
+    void* p = nullptr;
+    return noalloc_scratch(&p, "vita_noalloc_init");
+}
+
+size_t vita_generate_actions_noalloc_need_bytes(const vita_flownet_weights* fw, const vita_decoder_weights* dw, int32_t B, int32_t num_steps) {
+    SkbScope skb((size_t)VITA_NOALLOC_SPLITK_BYTES);
+    return vita_generate_actions_workspace_bytes(fw, dw, B, num_steps);
+}
+
+int vita_generate_actions_noalloc_f32(const float* obs_w, const float* obs_b, int32_t O, const vita_flownet_weights* fw,
+                                      const vita_decoder_weights* dw, const float* obs_features, int64_t ldobs, float* actions,
+                                      int64_t lda, float* latents_out, int32_t B, int32_t num_steps, vita_stream_t stream) {
+    const char* who = "vita_generate_actions_noalloc_f32";
+    VITA_TRY(generate_actions_checked(who, obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, B, num_steps));
+    if (B == 0) return VITA_OK;
+    SkbScope skb((size_t)VITA_NOALLOC_SPLITK_BYTES);
+    const size_t need = vita_generate_actions_workspace_bytes(fw, dw, B, num_steps);
+    if (need > (size_t)VITA_NOALLOC_SCRATCH_BYTES) {
+        set_error("%s: B=%d, num_steps=%d with these dims need %zu bytes of scratch, the built-in array holds %zu: use "
+                  "vita_generate_actions_f32 with a caller workspace", who, B, num_steps, need, (size_t)VITA_NOALLOC_SCRATCH_BYTES);
+        return VITA_ERR_WORKSPACE;
+    }
+    void* ws = nullptr;
+    VITA_TRY(noalloc_scratch(&ws, who));
+    return generate_actions_run(obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, latents_out, B, num_steps, ws,
                                 (hipStream_t)stream);
 }
 

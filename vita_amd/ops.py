@@ -274,6 +274,20 @@ def generate_actions(obs_w: Tensor, obs_b: Tensor, fw: FlowNetHandle, dw: Decode
     return (out, lat) if return_latents else out
 
 
+def generate_actions_noalloc(obs_w: Tensor, obs_b: Tensor, fw: FlowNetHandle, dw: DecoderHandle, obs_features: Tensor,
+                             num_steps: int, out: Tensor, latents_out: Optional[Tensor] = None) -> Tensor:
+    """vita_generate_actions_noalloc_f32: generate_actions on the library's built-in scratch array.  The caller passes every
+    input and output already in the layout the C ABI wants (fp32, contiguous rows); nothing is allocated here or inside."""
+    lib = L.load()
+    B, O = obs_features.shape
+    L.check(lib.vita_generate_actions_noalloc_f32(obs_w.data_ptr(), obs_b.data_ptr(), O, C.byref(fw.w), C.byref(dw.w),
+                                                  obs_features.data_ptr(), obs_features.stride(0), out.data_ptr(), out.stride(0),
+                                                  latents_out.data_ptr() if latents_out is not None else None, B, num_steps,
+                                                  _stream(obs_features)),
+            "vita_generate_actions_noalloc_f32")
+    return out
+
+
 # --------------------------------------------------------------------------------------
 # alternate matchers (inference): Consistency-FM sampler, SimpleMeanFlowNet + MeanFlow sampler
 # --------------------------------------------------------------------------------------
