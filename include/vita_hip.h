@@ -156,6 +156,15 @@ size_t vita_ode_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B,
 int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0,
                         float* x_out, int64_t ldo, int32_t B, int32_t num_steps, float* traj,
                         void* workspace, size_t workspace_bytes, vita_stream_t stream);
+/* Diagnostic, SYNCHRONISES (a blocking 4-byte copy; call it after the stream has been synchronised): at chip-filling
+ * batches vita_ode_sample_f32 runs all K steps as one persistent launch whose workgroups hand activations to each other
+ * through bounded waits.  *status = 0: the last solve on this workspace completed; != 0: a wait ran out in phase
+ * (*status - 1) and x_out is NOT valid (cannot happen while the launch's <= 256 workgroups are resident; the bound only
+ * guarantees that the kernel always ends).  VITA_NO_PERSISTENT=1 in the environment selects the per-launch path. */
+int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status);
+/* process-wide switch between the persistent launch (1, default unless VITA_NO_PERSISTENT=1) and the per-launch path (0);
+ * returns the previous setting.  Both produce the same bits. */
+int vita_ode_sample_set_persistent(int32_t on);
 
 /* ---------------------------------------------------------------------------------------
  * vita_decoder_forward_f32 — SimpleActionDecoder.forward (action_ae.py:267-279):

@@ -1,0 +1,104 @@
+"""The persistent Euler sampler (csrc/vita_ode_persistent.hip: all K steps of TorchFlowMatcher.sample, flow_matchers.py:41-79,
+in one launch whose workgroups hand activations to each other) against the per-launch path it replaces at chip-filling
+batches: same tiles and epilogues, so the SAME BITS; and against the fp64 oracle on sampled rows."""
+import pytest
+import torch
+
+from oracle import vita_oracle as O
+from vita_amd import ops
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _restore_switch():
+    prev = ops.set_persistent_sampler(True)
+    yield
+    ops.set_persistent_sampler(prev)
+
+
+def both_paths(fw, x0, K, traces=False):
+    ops.set_persistent_sampler(True)
+    a = ops.ode_sample(fw, x0, K, return_traces=traces)
+    assert ops.ode_sample_status(fw, x0.shape[0], K, DEV) == 0
+    ops.set_persistent_sampler(False)
+    b = ops.ode_sample(fw, x0, K, return_traces=traces)
+    torch.cuda.synchronize()
+    ops.set_persistent_sampler(True)
+    return a, b
+
+
+@pytest.mark.parametrize("B,K", [(4096, 6), (4096, 1), (8192, 3)])
+def test_persistent_equals_per_launch_path_bitwise(B, K):
+    sd = O.make_state_dict(533, 21, seed=0)
+    fw = ops.FlowNetHandle(sd, DEV)
+    x0 = torch.randn(B, 512, generator=torch.Generator().manual_seed(B + K)).to(DEV)
+    a, b = both_paths(fw, x0, K)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b), (a - b).abs().max().item()
+    # and it is the reference's arithmetic: sampled rows against the fp64 oracle (tolerance of the headline path: 1e-5)
+    idx = torch.arange(0, B, B // 8)
+    ref = O.euler_sample({k: v.double() for k, v in sd.items()}, x0[idx].cpu().double(), K)
+    err = ((a[idx].cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-5, err
+
+
+def test_persistent_trajectory_and_repeatability():
+    """return_traces (flow_matchers.py:63-66,73-75): every x_k of the trajectory, bitwise; ten solves in a row on the same
+    buffers (consumers' L1 warm with the previous solve's lines) give the same bits every time."""
+    sd = O.make_state_dict(555, 7, seed=3)
+    fw = ops.FlowNetHandle(sd, DEV)
+    x0 = torch.randn(4096, 512, generator=torch.Generator().manual_seed(11)).to(DEV)
+    (a, ta), (b, tb) = both_paths(fw, x0, 4, traces=True)
+    assert torch.equal(ta, tb) and torch.equal(a, b) and torch.equal(ta[0], x0) and torch.equal(ta[-1], a)
+    first = ops.ode_sample(fw, x0, 6).clone()
+    for _ in range(10):
+        again = ops.ode_sample(fw, x0, 6)
+        assert torch.equal(again, first)
+    assert ops.ode_sample_status(fw, 4096, 6, DEV) == 0
+
+
+def test_persistent_under_uneven_load():
+    """Hand-offs must not depend on timing or placement: the same solve while another stream keeps part of the chip busy
+    with unrelated streaming kernels (workgroups start late, teams drift apart) gives the same bits."""
+    sd = O.make_state_dict(533, 21, seed=0)
+    fw = ops.FlowNetHandle(sd, DEV)
+    x0 = torch.randn(4096, 512, generator=torch.Generator().manual_seed(5)).to(DEV)
+    want = ops.ode_sample(fw, x0, 6).clone()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream(DEV)
+    junk = torch.randn(64 << 20, device=DEV)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                junk.mul_(1.0001)
+        got = ops.ode_sample(fw, x0, 6)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), rep
+    assert ops.ode_sample_status(fw, 4096, 6, DEV) == 0
+
+
+def test_wide_net_takes_the_persistent_launch():
+    """BASELINE configs[4]: hidden_dim 1024 (teams of 32 workgroups, 8 row groups per launch)."""
+    sd = O.make_state_dict(533, 21, hidden_dim=1024, seed=1)
+    fw = ops.FlowNetHandle(sd, DEV)
+    x0 = torch.randn(2048, 512, generator=torch.Generator().manual_seed(6)).to(DEV)
+    a, b = both_paths(fw, x0, 2)
+    assert torch.equal(a, b)
+    idx = torch.arange(0, 2048, 256)
+    ref = O.euler_sample({k: v.double() for k, v in sd.items()}, x0[idx].cpu().double(), 2)
+    assert ((a[idx].cpu().double() - ref).abs().max() / ref.abs().max()).item() <= 1e-5
+
+
+def test_generate_actions_uses_it_and_matches():
+    sd = O.make_state_dict(533, 21, seed=0)
+    fw, dw = ops.FlowNetHandle(sd, DEV), ops.DecoderHandle(sd, DEV)
+    ow, ob = sd["obs_encoder.weight"].to(DEV), sd["obs_encoder.bias"].to(DEV)
+    obs = torch.randn(4096, 533, generator=torch.Generator().manual_seed(7)).to(DEV)
+    ops.set_persistent_sampler(True)
+    a = ops.generate_actions(ow, ob, fw, dw, obs, 6)
+    ops.set_persistent_sampler(False)
+    b = ops.generate_actions(ow, ob, fw, dw, obs, 6)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)

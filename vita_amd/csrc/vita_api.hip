@@ -34,6 +34,7 @@ struct SkbScope {
 struct FlowWs {
     float *sk, *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
     float *stat, *c1, *c2, *c1f, *c2f;   // folded LayerNorm (sampling at large batch): row statistics and the c-tables
+    float* sync;                         // hand-off state of the persistent sampler (team counters, timeout / status words)
     size_t bytes;
 };
 
@@ -60,8 +61,9 @@ static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, 
     f.hn = c.take((size_t)B * w->H);
     f.u = c.take((size_t)B * w->FF);
     f.x = need_x ? c.take((size_t)B * w->D) : nullptr;
-    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = nullptr;
+    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = f.sync = nullptr;
     if (T != B && use_ln_fold(w, B)) {   // sampling only (per-row t has per-row modulation: no shared tables)
+        f.sync = c.take(ode_persistent_sync_bytes(T, w->L) / sizeof(float));
         f.stat = c.take((size_t)(w->H / 128) * B * 2);
         f.c1 = c.take((size_t)T * w->L * w->FF);
         f.c2 = c.take((size_t)T * w->L * w->FF);
@@ -183,6 +185,15 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
     const float dt = (float)(1.0 / (double)K);  // python float 1.0/num_steps, rounded to fp32 at the multiply
     if (traj)
         VITA_CHECK_HIP(hipMemcpy2DAsync(traj, (size_t)D * 4, x0, (size_t)ldx0 * 4, (size_t)D * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
+    if (fold && ode_persistent_eligible(w, B, x0, ldx0, x_out, ldo)) {
+        // all K steps in one persistent launch (vita_ode_persistent.hip): same tiles, same epilogues, same bits
+        VITA_TRY(launch_ode_persistent(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.hn, f.u, f.stat, f.mod, f.c1, f.c2, f.c1f, f.c2f,
+                                       f.sync, s));
+        if (traj)
+            VITA_CHECK_HIP(hipMemcpy2DAsync(x_out, (size_t)ldo * 4, traj + (size_t)K * B * D, (size_t)D * 4, (size_t)D * 4, (size_t)B,
+                                            hipMemcpyDeviceToDevice, s));
+        return VITA_OK;
+    }
     const float* src = x0;
     int64_t lds = ldx0;
     for (int k = 0; k < K; ++k) {
@@ -340,6 +351,19 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
     VITA_REQUIRE(x0 && x_out && ldx0 >= w->D && ldo >= w->D, "vita_ode_sample_f32: bad x0/x_out");
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_ode_sample_workspace_bytes(w, B, num_steps), "vita_ode_sample_f32"));
     return ode_sample(w, x0, ldx0, x_out, ldo, B, num_steps, traj, workspace, (hipStream_t)stream);
+}
+
+int vita_ode_sample_set_persistent(int32_t on) { return set_ode_persistent(on); }
+
+int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status) {
+    VITA_REQUIRE(w && workspace && status && B > 0 && num_steps > 0, "vita_ode_sample_status: bad arguments");
+    *status = 0;
+    FlowWs f = carve_flow(const_cast<void*>(workspace), w, B, num_steps, false);
+    if (f.sync == nullptr) return VITA_OK;      // shapes that never take the persistent launch
+    unsigned v = 0;
+    VITA_CHECK_HIP(hipMemcpy(&v, reinterpret_cast<const char*>(f.sync) + ode_persistent_status_offset(), sizeof(v), hipMemcpyDeviceToHost));
+    *status = (int32_t)v;
+    return VITA_OK;
 }
 
 size_t vita_consistency_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {

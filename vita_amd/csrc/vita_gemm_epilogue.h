@@ -115,7 +115,23 @@ __device__ __forceinline__ float epi_elem(float acc, float bias, float zin, floa
 // KG > 1: the workgroup's waves form KG groups that each reduced a slice of every k-tile over the SAME output tile
 // (in-workgroup split-K); group kg parks its partial tile in region kg of obuf and the row phase sums the regions in
 // index order (deterministic).  obuf then needs KG * BM * (BN + 4) floats.
-template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD, int KG = 1>
+// 16-byte / 8-byte stores that write through to the fabric (`sc1`): the payload stores of an in-launch hand-off to other
+// workgroups (MI355X: per-XCD L2s are not coherent with each other; a write-through store needs no L2 write-back release).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base) {
+    // the whole 4 GiB window above `base`: the callers' offsets are validated on the host (every buffer is far smaller)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0xFFFFFFFFu, 0x00020000);
+}
+__device__ __forceinline__ void store16_wt(__amdgpu_buffer_rsrc_t r, int64_t elem_off, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)(elem_off * 4), 0, 16);
+}
+__device__ __forceinline__ void store8_wt(__amdgpu_buffer_rsrc_t r, int64_t elem_off, float a, float b) {
+    u32x2_t v = {__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b)};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(elem_off * 4), 0, 16);
+}
+
+template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD, int KG = 1, bool SC1 = false>
 __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
                                               int lane, int tid, int kg = 0, const float* srow = nullptr) {
     constexpr int S = BN + 4;
@@ -191,6 +207,10 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
             if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
             if (gate_vec) gv = *reinterpret_cast<const f32x4*>(e.gate + col);
             f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, am = c1;
+            __amdgpu_buffer_rsrc_t rs_y, rs_aux, rs_stat;
+            if constexpr (SC1) {
+                rs_y = wt_rsrc(e.Y); rs_aux = wt_rsrc(e.aux_out); rs_stat = wt_rsrc(e.stat_out);
+            }
             if (e.ln_stats) c1 = *reinterpret_cast<const f32x4*>(e.ln_c1 + col);
             if (e.aux_out) {
                 am = *reinterpret_cast<const f32x4*>(e.aux_mul + col);
@@ -224,7 +244,11 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                     pre[k] = p_;
                 }
                 if (e.preact) *reinterpret_cast<f32x4*>(e.preact + row * e.ld_preact + col) = pre;
-                if (e.Y) *reinterpret_cast<f32x4*>(e.Y + row * e.ldy + col) = out;
+                if constexpr (SC1) {
+                    if (e.Y) store16_wt(rs_y, row * e.ldy + col, out);
+                } else {
+                    if (e.Y) *reinterpret_cast<f32x4*>(e.Y + row * e.ldy + col) = out;
+                }
                 if (e.ybf) {
                     u16x4 hb;
 #pragma unroll
@@ -232,7 +256,8 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                     *reinterpret_cast<u16x4*>(e.ybf + row * e.ld_ybf + col) = hb;
                 }
                 if (e.aux_out) {
-                    *reinterpret_cast<f32x4*>(e.aux_out + row * e.ld_aux + col) = out * am;
+                    if constexpr (SC1) store16_wt(rs_aux, row * e.ld_aux + col, out * am);
+                    else *reinterpret_cast<f32x4*>(e.aux_out + row * e.ld_aux + col) = out * am;
                     if constexpr (C4 == 32) {
                         // a row's BN = 128 outputs sit in 32 consecutive lanes.  (mean, M2) in ONE shuffle chain: sums of
                         // d = x - x0 and d^2 with x0 the row's first element (shifted one-pass: no cancellation against the mean)
@@ -244,9 +269,10 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                         sm = half_wave_sum(sm);
                         q = half_wave_sum(q);
                         if ((tid & 31) == 0) {
-                            float* st = e.stat_out + ((int64_t)(n0 / BN) * e.M + row) * 2;
-                            st[0] = x0 + sm * (1.0f / (float)BN);
-                            st[1] = q - sm * sm * (1.0f / (float)BN);
+                            const int64_t so = ((int64_t)(n0 / BN) * e.M + row) * 2;
+                            const float s0 = x0 + sm * (1.0f / (float)BN), s1 = q - sm * sm * (1.0f / (float)BN);
+                            if constexpr (SC1) store8_wt(rs_stat, so, s0, s1);
+                            else { e.stat_out[so] = s0; e.stat_out[so + 1] = s1; }
                         }
                     }
                 }
@@ -311,10 +337,14 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
 
 // run-time activation -> compile-time dispatch.  BACKWARD = false: forward GEMMs (act = the activation applied);
 // BACKWARD = true: the transposed-operand GEMMs (act = the activation whose derivative is applied from act_grad_z).
-template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD, int KG = 1>
+template <int BM, int BN, int MI, int NI, int NT_, bool BACKWARD, int KG = 1, bool SC1 = false, int FACT = -1>
 __device__ __forceinline__ void epilogue_dispatch(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
                                                   int lane, int tid, int kg = 0, const float* srow = nullptr) {
-#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg, srow)
+#define VITA_EPI(A) epilogue_tile<BM, BN, MI, NI, NT_, A, BACKWARD, KG, SC1>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg, srow)
+    if constexpr (FACT >= 0) {      // activation fixed at compile time (persistent sampler): one instantiation, no split-K form
+        epilogue_tile<BM, BN, MI, NI, NT_, FACT, BACKWARD, KG, SC1>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg, srow);
+        return;
+    }
     if (e.partial != nullptr || (BACKWARD && e.act_grad_z == nullptr)) {
         epilogue_tile<BM, BN, MI, NI, NT_, VITA_ACT_NONE, false, KG>(acc, obuf, e, m0, n0, wm, wn, lane, tid, kg);
         return;

@@ -19,6 +19,14 @@ int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t st
 // c-tables of the folded LayerNorm for T steps: c1[(k*L+l)*FF + j] = sum_i (1 + scale_kl[i]) W1_l[j][i], c2 likewise from the shifts
 // (+ b1); c1f/c2f (D) for norm -> out_proj.  One launch (vita_elementwise.hip).
 int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s);
+// the persistent Euler sampler (vita_ode_persistent.hip): one launch for all K steps at chip-filling batches
+bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* x0, int64_t ldx0, const float* x_out, int64_t ldo);
+size_t ode_persistent_sync_bytes(int K, int L);
+int set_ode_persistent(int on);   // returns the previous setting
+size_t ode_persistent_status_offset();
+int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
+                          float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,
+                          const float* c1f, const float* c2f, void* sync, hipStream_t s);
 int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
 int launch_step_times(float* ts, int K, hipStream_t s);
 int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,

@@ -234,6 +234,24 @@ def ode_sample(fw: FlowNetHandle, x0: Tensor, num_steps: int, return_traces: boo
     return (out, traj) if return_traces else out
 
 
+def ode_sample_status(fw: FlowNetHandle, B: int, num_steps: int, device) -> int:
+    """vita_ode_sample_status for the cached workspace the last ode_sample on `device` used (synchronises): 0 = the
+    persistent launch completed, != 0 = a bounded hand-off wait ran out in phase status - 1."""
+    lib = L.load()
+    torch.cuda.synchronize(device)
+    nbytes = lib.vita_ode_sample_workspace_bytes(C.byref(fw.w), B, num_steps)
+    ws = workspace(torch.device(device), nbytes)
+    st = C.c_int32(0)
+    L.check(lib.vita_ode_sample_status(C.byref(fw.w), B, num_steps, ws.data_ptr(), C.byref(st)), "vita_ode_sample_status")
+    return int(st.value)
+
+
+def set_persistent_sampler(on: bool) -> bool:
+    """Process-wide switch of vita_ode_sample_f32 / vita_generate_actions_f32 between the persistent launch and the
+    per-launch path; returns the previous setting."""
+    return bool(L.load().vita_ode_sample_set_persistent(1 if on else 0))
+
+
 def decoder_forward(dw: DecoderHandle, z: Tensor) -> Tensor:
     """SimpleActionDecoder.forward (action_ae.py:267-279); returns (B, OUT)."""
     lib = L.load()
