@@ -79,16 +79,23 @@ def test_persistent_under_uneven_load():
     assert ops.ode_sample_status(fw, 4096, 6, DEV) == 0
 
 
-def test_wide_net_takes_the_persistent_launch():
-    """BASELINE configs[4]: hidden_dim 1024 (teams of 32 workgroups, 8 row groups per launch)."""
-    sd = O.make_state_dict(533, 21, hidden_dim=1024, seed=1)
+def test_other_team_size_and_two_tiles_per_member():
+    """hidden_dim 256: teams of 8 workgroups, 32 row groups per launch, and out_proj has 16 tiles per row group, two per
+    member (the tile loop inside a phase).  (hidden_dim 1024 would need teams of 32: measured slower than the per-launch
+    path, so that shape stays on it — both switches then run the same code.)"""
+    sd = O.make_state_dict(533, 21, hidden_dim=256, seed=1)
     fw = ops.FlowNetHandle(sd, DEV)
-    x0 = torch.randn(2048, 512, generator=torch.Generator().manual_seed(6)).to(DEV)
+    x0 = torch.randn(8192, 512, generator=torch.Generator().manual_seed(6)).to(DEV)
     a, b = both_paths(fw, x0, 2)
     assert torch.equal(a, b)
-    idx = torch.arange(0, 2048, 256)
+    idx = torch.arange(0, 8192, 1024)
     ref = O.euler_sample({k: v.double() for k, v in sd.items()}, x0[idx].cpu().double(), 2)
     assert ((a[idx].cpu().double() - ref).abs().max() / ref.abs().max()).item() <= 1e-5
+    sdw = O.make_state_dict(533, 21, hidden_dim=1024, seed=1)
+    fww = ops.FlowNetHandle(sdw, DEV)
+    xw = x0[:2048].contiguous()
+    aw, bw = both_paths(fww, xw, 2)
+    assert torch.equal(aw, bw)
 
 
 def test_generate_actions_uses_it_and_matches():

@@ -354,6 +354,7 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
 }
 
 int vita_ode_sample_set_persistent(int32_t on) { return set_ode_persistent(on); }
+int vita_debug_ode_stamps(void* device_buf) { set_ode_persistent_stamps(device_buf); return VITA_OK; }
 
 int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status) {
     VITA_REQUIRE(w && workspace && status && B > 0 && num_steps > 0, "vita_ode_sample_status: bad arguments");

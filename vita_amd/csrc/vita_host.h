@@ -23,6 +23,7 @@ int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, i
 bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* x0, int64_t ldx0, const float* x_out, int64_t ldo);
 size_t ode_persistent_sync_bytes(int K, int L);
 int set_ode_persistent(int on);   // returns the previous setting
+void set_ode_persistent_stamps(void* device_buf);
 size_t ode_persistent_status_offset();
 int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
                           float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,

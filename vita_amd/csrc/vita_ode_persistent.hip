@@ -55,6 +55,17 @@ struct OdeParams {
     int TS;
 };
 
+__device__ __forceinline__ unsigned long long clock64_shader() {   // shader clock (follows DVFS)
+    unsigned long long t;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+__device__ __forceinline__ unsigned long long clock64_real() {     // 100 MHz constant clock
+    unsigned long long t;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    return t;
+}
+
 // the consumer half of the hand-off; run by all threads between the weight prefetch and the first dependent load
 struct TeamSync {
     unsigned* cnt;
@@ -63,6 +74,7 @@ struct TeamSync {
     unsigned limit;
     unsigned code;        // what a timeout writes into the timeout word (phase + 1)
     float* flag;          // one LDS word
+    unsigned long long* stamp;   // diagnostic (NULL in normal use): receives the clock when the wait ended
     __device__ __forceinline__ bool operator()() const {
         if (target == 0) return true;
         if (threadIdx.x == 0) {
@@ -79,6 +91,7 @@ struct TeamSync {
                 __hip_atomic_store(tmo, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(tmo + (kStickyWord - kMaxTeams * kTeamStride), code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (stamp) *stamp = clock64_real();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // ONE acquire after the poll has matched
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // ... completed before the barrier lets anyone load
             *reinterpret_cast<volatile unsigned*>(flag) = ok;
@@ -169,6 +182,7 @@ struct PersistArgs {
     unsigned* sync;
     int nphases, TS, rg0;
     unsigned spin_limit;
+    unsigned long long* stamps;   // diagnostic: NULL, or [workgroup][phase][6] clocks: 100 MHz (phase start, wait over, tiles done, published), shader (start, published)
 };
 
 __global__ __launch_bounds__(DNT, 2) void ode_persistent_kernel(PersistArgs q) {
@@ -196,7 +210,9 @@ __global__ __launch_bounds__(DNT, 2) void ode_persistent_kernel(PersistArgs q) {
     for (int phase = 0; phase < q.nphases; ++phase) {     // phases this workgroup has completed == the team's, once all arrived
         const PhaseDesc& d = table[phase];
         // one phase: wait for the team, run this member's tiles, publish
-        TeamSync sy{cnt, tmo, (unsigned)(TS * phase), q.spin_limit, (unsigned)phase + 1u, flag};
+        unsigned long long* st = q.stamps ? q.stamps + ((size_t)blockIdx.x * q.nphases + phase) * 6 : nullptr;
+        if (st && tid == 0) { st[0] = clock64_real(); st[1] = st[0]; st[4] = clock64_shader(); }
+        TeamSync sy{cnt, tmo, (unsigned)(TS * phase), q.spin_limit, (unsigned)phase + 1u, flag, st ? st + 1 : nullptr};
         bool first = true;
         const int ntiles = d.ntiles;
         for (int t = member; t < ntiles; t += TS) {
@@ -213,8 +229,10 @@ __global__ __launch_bounds__(DNT, 2) void ode_persistent_kernel(PersistArgs q) {
             first = false;
         }
         if (first && !sy()) return;                        // no tile in this phase: still keep in step with the team
+        if (st && tid == 0) st[2] = clock64_real();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every wave: its write-through stores have left
         __syncthreads();                                    // ... all of them; and the stage buffers are free again
+        if (st && tid == 0) { st[3] = clock64_real(); st[5] = clock64_shader(); }
         if (tid == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -229,6 +247,8 @@ static bool persistent_disabled() {
     }
     return v == 0;
 }
+static std::atomic<unsigned long long*> g_stamps{nullptr};
+void set_ode_persistent_stamps(void* device_buf) { g_stamps.store(static_cast<unsigned long long*>(device_buf)); }
 int set_ode_persistent(int on) {
     const bool was_off = persistent_disabled();
     g_persistent.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -247,7 +267,9 @@ bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* 
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
     if (w->L < 1 || w->H % 128 || w->FF % 128 || w->D % 128 || w->H > 2048 || B % 256) return false;
     const int TS = w->FF / 128;
-    if (TS > 256 || 256 % TS) return false;
+    // teams of up to 16 workgroups (H <= 512 at mlp_ratio 4): measured at H = 1024 (teams of 32) the persistent launch is 4 %
+    // slower than the per-launch path (profiles/r02_persistent_vs_per_launch.jsonl), at H = 512 equal
+    if (TS > 16 || 256 % TS) return false;
     const int rg_per_launch = 256 / TS;
     if ((B / 256) % rg_per_launch) return false;
     if (!al(x0) || !al(x_out) || ldx0 % 4 || ldo % 4) return false;
@@ -276,6 +298,7 @@ int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_
     PersistArgs a{};
     a.table = table; a.sync = static_cast<unsigned*>(sync); a.nphases = nphases; a.TS = TS;
     a.spin_limit = 1u << 22;      // ~ seconds: only a lost workgroup gets there
+    a.stamps = g_stamps.load();
     for (int rg0 = 0; rg0 < B / 256; rg0 += rg_per_launch) {
         a.rg0 = rg0;
         // counters + timeout word before every launch; the sticky status word only with the call's first launch
