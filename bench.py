@@ -243,7 +243,7 @@ def main():
                 "normalised_max_error_vs_f32_path": float(f"{err:.3g}"), "stated_tolerance": 2e-2}
 
     # ---- training leg: data-parallel train_step (normalize -> fused fwd+bwd -> bucketed all-reduce -> clip+AdamW+EMA)
-    def train_leg(TB, gemm_dtype, nts, all_ranks):
+    def train_leg(TB, gemm_dtype, nts, all_ranks, group=None):
         from vita_amd.config import default_config
         from vita_amd.policy import VitaPolicy
         from vita_amd.trainer import PolicyTrainer
@@ -255,7 +255,7 @@ def main():
         torch.manual_seed(0)
         pol = VitaPolicy(cfg, stats)
         pol.load_state_dict({k: v for k, v in sd.items()}, strict=False)
-        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100000)
+        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100000, group=group)
         gt = torch.Generator().manual_seed(100 + rank)
         ncam = len(cfg.task.image_keys)
         tbatch = {cfg.task.state_key: torch.randn(TB, 1, S, generator=gt).to(dev),
@@ -299,6 +299,16 @@ def main():
         print("bench.py: the training leg uses the default policy dims; skipped for --hidden != 512", file=sys.stderr)
     if not args.no_train and args.hidden == 512:
         train = train_leg(args.train_batch, "f32", args.train_steps or args.steps, True)
+        if world > 1:
+            # the same step without the collective (each rank alone in a one-rank group): what the all-reduce leaves exposed
+            try:
+                solo_groups = [dist.new_group([r]) for r in range(world)]
+                solo = train_leg(args.train_batch, "f32", args.train_steps or args.steps, False, group=solo_groups[rank])
+                train["ms_per_step_without_allreduce"] = solo["ms_per_step"]
+                train["exposed_communication_ms_per_step"] = round(train["ms_per_step"] - solo["ms_per_step"], 4)
+            except Exception as e:      # a side figure must never cost the scaling line
+                train["exposed_communication_ms_per_step"] = None
+                train["exposed_communication_error"] = repr(e)[:200]
         if world == 1 and args.train_large_batch > 0:
             # side figures at a batch that fills the chip: fp32, and BASELINE configs[2]'s bf16-operand training
             train_large = train_leg(args.train_large_batch, "f32", 5, False)

@@ -374,6 +374,10 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
                                       forked from and joined back into `stream` with events; grad_ready[0] is then recorded on a side
                                       stream.  Same bits as the single-stream order.  Measured on MI355X: the branches do not overlap
                                       the main chain's small kernels (B=128 step 3.34 -> 3.44 ms), hence off by default */
+    int32_t grad_ready_layers;     /* 1: `grad_ready` holds 3 + L events; entry 3 + l is recorded when the gradients of
+                                      flow_net.layers.l.mlp.{fc1,fc2}.{weight,bias} are final (their stacked weight-gradient GEMMs run
+                                      layer by layer after the input-gradient chains), so a data-parallel caller can start that
+                                      layer's all-reduce while the following layers' weight gradients are still being computed */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,
@@ -400,7 +404,8 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
  * d_obs_features: NULL or (B,O) receiving d loss / d obs_features — what flows on into a trainable observer
  *   (the ResNet backbone is in the reference's single AdamW group, vita_policy.py:222-229).
  * grad_ready: NULL or 3 hipEvent_t recorded on `stream` when (0) the decoder's, (1) the flow net's, (2) every
- *   gradient is final — the points at which a data-parallel caller starts that bucket's all-reduce. */
+ *   gradient is final — the points at which a data-parallel caller starts that bucket's all-reduce; with
+ *   cfg->grad_ready_layers, 3 + L events (see vita_loss_config). */
 size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B);
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t,
@@ -505,6 +510,7 @@ int vita_meanflow_sample_f32(const vita_meanflow_weights* w, const float* x0, in
  *   losses: device float[VITA_MF_LOSS_COUNT], indexed by VITA_MF_LOSS_*.
  *   grads: NULL = forward only; else every gradient buffer is overwritten (without use_imf the v head's with zeros: it takes no part).
  *   d_obs_features: NULL or (B,O) receiving d loss / d obs_features (needs grads), as in vita_compute_loss_f32.
+ *   grad_ready: NULL or 3 hipEvent_t, recorded as in vita_compute_loss_f32 (decoder / flow net / all gradients final).
  * use_imf = 1 is improved MeanFlow (flow_matcher.name = "improved_mean", :137-163).
  */
 typedef struct vita_meanflow_policy_weights {
@@ -544,8 +550,8 @@ size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_wei
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
                                    const float* t, const float* r, const float* enc_noise, int32_t B, float* losses,
-                                   float* d_obs_features, int64_t ld_dobs, void* workspace, size_t workspace_bytes,
-                                   vita_stream_t stream);
+                                   float* d_obs_features, int64_t ld_dobs, void* const* grad_ready, void* workspace,
+                                   size_t workspace_bytes, vita_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -405,3 +405,30 @@ def test_full_size_training_step_properties_b4096():
     assert worst[0] <= 2e-5, worst
     worst = max((nerr((g_a[k] + g_b[k]) * 0.5, g_all[k]), k) for k in sd if k.startswith("action_encoder.encoder."))
     assert worst[0] <= 5e-3, worst
+
+
+def test_forked_child_of_a_gpu_process_fails_loudly():
+    """HIP cannot be used in a fork()ed child of a process that initialised it; calls through the ctypes binding used to hang
+    there (round 1).  The binding now marks such a child and raises before any HIP call."""
+    import os
+    torch.zeros(1, device=DEV)          # this process holds a HIP context
+    L.load()
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:                        # child: no GPU call may happen here
+        code = 1
+        try:
+            from vita_amd import ops
+            try:
+                ops.sumsq  # noqa: B018
+                L.load()
+            except L.VitaHipError as e:
+                code = 0 if "fork" in str(e) else 2
+        finally:
+            os.write(w, bytes([code]))
+            os._exit(0)
+    os.close(w)
+    got = os.read(r, 1)
+    os.waitpid(pid, 0)
+    os.close(r)
+    assert got == b"\x00", got

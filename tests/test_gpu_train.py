@@ -227,13 +227,13 @@ def case_sd(tiny, tag):
     return {k[len(p):]: v for k, v in tiny.items() if k.startswith(p)}
 
 
-def run_fused(ops, dev, sd, obs, actions, t, cfg, pair_j=None, pair_i=None):
+def run_fused(ops, dev, sd, obs, actions, t, cfg, pair_j=None, pair_i=None, enc_noise=None):
     sdd = {k: v.to(dev).contiguous() for k, v in sd.items()}
     gsd = {k: torch.full_like(v, float("nan")) for k, v in sdd.items()}   # must be fully overwritten
     pw = ops.PolicyHandle(sdd, dev, pred_horizon=actions.shape[1], strict=True)
     gw = ops.PolicyHandle(gsd, dev, pred_horizon=actions.shape[1], strict=True)
     losses, dobs = ops.compute_loss(pw, cfg, obs.to(dev), actions.to(dev), t.to(dev), grads=gw, pair_j=pair_j, pair_i=pair_i,
-                                    need_dobs=True)
+                                    need_dobs=True, enc_noise=enc_noise.to(dev) if enc_noise is not None else None)
     torch.cuda.synchronize()
     return losses.cpu(), {k: v.cpu() for k, v in gsd.items()}, dobs.cpu()
 
@@ -339,6 +339,25 @@ def test_compute_loss_default_dims_b128_vs_oracle_fp64(ops, dev):
     # determinism (identity pairing: no atomics anywhere)
     losses2, grads2, _ = run_fused(ops, dev, sd, obs, actions, t, ops.loss_config(num_steps=6))
     assert torch.equal(losses, losses2) and all(torch.equal(grads[k], grads2[k]) for k in sd)
+
+
+def test_compute_loss_large_batch_transposed_weight_dgrads_vs_oracle_fp64(ops, dev):
+    """B >= 1024: the step keeps transposed copies of the weights, so every input-gradient GEMM (dX = dY . W) runs as a
+    row-operand GEMM on the LDS-DMA kernels with the act'(z) epilogue.  Small feature dims keep the fp64 oracle cheap; the
+    variational CNN encoder and an explicit pairing are on so that every registered weight class is exercised."""
+    A, T, B = 7, 16, 1280
+    sd = O.make_state_dict(40, A, latent_dim=64, hidden_dim=64, num_layers=2, mlp_ratio=4, pred_horizon=T, ae_hidden=48, ae_layers=4,
+                           time_embed_dim=32, seed=15, variational=True)
+    g = torch.Generator().manual_seed(16)
+    obs, actions, t = torch.randn(B, 40, generator=g), torch.randn(B, T, A, generator=g), torch.rand(B, generator=g)
+    noise = torch.randn(B, 64, generator=g)
+    kw = dict(num_steps=3, kl_weight=0.01, enc_noise=noise.double())
+    m, gref, dobs_ref = oracle_grads(sd, obs, actions, t, **kw)
+    losses, grads, dobs = run_fused(ops, dev, sd, obs, actions, t, ops.loss_config(num_steps=3, kl_weight=0.01), enc_noise=noise)
+    assert abs(losses[0].item() - m["loss"].item()) <= 1e-5 * abs(m["loss"].item())
+    worst = max((nerr(grads[k], gref[k]), k) for k in sd)
+    assert worst[0] <= 5e-5, f"worst gradient error {worst}"
+    close(dobs, dobs_ref, 5e-5, "d obs_features")
 
 
 def test_compute_loss_forward_only_and_action_encoder(ops, dev, tiny):

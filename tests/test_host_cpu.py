@@ -232,3 +232,26 @@ def test_bench_self_launches_one_process_per_gpu():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-launch"], env=dict(env, WORLD_SIZE="3", RANK="0"),
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "WORLD_SIZE=3" in r.stderr
+
+
+def test_reduce_plan_covers_the_flat_buffer_once_in_firing_order():
+    """The data-parallel reduce plan: every hot-path parameter in exactly one segment; decoder first, then one segment per
+    flow-net layer's fc1 / fc2 gradients (events 3 + l), then the rest of the flow net, then the encoders."""
+    import torch
+    from vita_amd.config import default_config
+    from vita_amd.policy import VitaPolicy
+    cfg = default_config("pusht")
+    stats = {"observation.state": {"mean": [0.0, 0.0], "std": [1.0, 1.0]}, "action": {"mean": [0.0, 0.0], "std": [1.0, 1.0]}}
+    pol = VitaPolicy(cfg, stats)
+    plan = pol.reduce_plan()
+    n = sum(p.numel() for _, p in pol.hot_path_named_parameters())
+    cover = torch.zeros(n, dtype=torch.int32)
+    for lo, hi, ev in plan:
+        cover[lo:hi] += 1
+    assert bool((cover == 1).all())
+    L_ = cfg.policy.flow_net.num_layers
+    evs = [ev for _, _, ev in plan]
+    assert evs[0] == 0 and evs[-1] == 2 and evs[1:1 + L_] == [3 + l for l in range(L_)] and set(evs[1 + L_:-1]) == {1}
+    H = cfg.policy.flow_net.hidden_dim
+    per_layer = 2 * H * 4 * H + 4 * H + H          # fc1 (4H x H) + fc2 (H x 4H) + their biases
+    assert all(hi - lo == per_layer for lo, hi, ev in plan if ev >= 3)

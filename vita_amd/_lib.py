@@ -103,7 +103,7 @@ class LossConfig(C.Structure):
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
         ("kl_weight", C.c_float), ("gemm_bf16", C.c_int32),
-        ("fm_kind", C.c_int32), ("fm_sigma", C.c_float), ("side_streams", C.c_int32),
+        ("fm_kind", C.c_int32), ("fm_sigma", C.c_float), ("side_streams", C.c_int32), ("grad_ready_layers", C.c_int32),
     ]
 
 
@@ -233,7 +233,7 @@ SIGNATURES = {
     "vita_compute_loss_meanflow_workspace_bytes": (C.c_size_t, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowLossConfig), C.c_int32]),
     "vita_compute_loss_meanflow_f32": (C.c_int, [C.POINTER(MeanFlowPolicyWeights), C.POINTER(MeanFlowPolicyWeights),
                                                  C.POINTER(MeanFlowLossConfig), c_fp, C.c_int64, c_fp, c_fp, c_fp, c_fp, C.c_int32, c_fp,
-                                                 c_fp, C.c_int64, c_fp, C.c_size_t, c_fp]),
+                                                 c_fp, C.c_int64, C.POINTER(c_fp), c_fp, C.c_size_t, c_fp]),
     "vita_normalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_unnormalize_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int64, c_fp]),
     "vita_layernorm_modulate_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_int32,
@@ -242,16 +242,48 @@ SIGNATURES = {
 }
 
 _lib = None
+_bad_fork = False
 
 
 class VitaHipError(RuntimeError):
     pass
 
 
+_gpu_live_before_fork = False
+
+
+def _before_fork():
+    """In the parent, just before fork(): does this process hold a HIP context that the library may have used?  (Asked here
+    because torch.cuda.is_initialized() answers False inside a forked child.)"""
+    global _gpu_live_before_fork
+    try:
+        import sys
+        torch = sys.modules.get("torch")
+        _gpu_live_before_fork = bool(_lib is not None and torch is not None and torch.cuda.is_initialized())
+    except Exception:
+        _gpu_live_before_fork = False
+
+
+def _after_fork_in_child():
+    """HIP, like CUDA, cannot be used in a fork()ed child of a process that had initialised it (the runtime's threads and
+    its queues belong to the parent).  torch raises for its own calls ("Cannot re-initialize CUDA in forked subprocess");
+    calls that go straight to HIP through this ctypes binding bypass that check and HUNG intermittently on the GPU box
+    (round 1, tests/test_gpu_00_dp.py).  Mark the child so that load() fails loudly instead."""
+    global _bad_fork
+    if _gpu_live_before_fork:
+        _bad_fork = True
+
+
+os.register_at_fork(before=_before_fork, after_in_child=_after_fork_in_child)
+
+
 def load() -> C.CDLL:
     """Load libvita_hip.so and bind every symbol the header declares.  Raises if the
     library has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
     global _lib
+    if _bad_fork:
+        raise VitaHipError("this process was fork()ed from one that had initialised the GPU: HIP cannot be used here. Start worker "
+                           "processes with the 'spawn' method (torch.multiprocessing.get_context('spawn')), or fork before any GPU call")
     if _lib is not None:
         return _lib
     if not os.path.exists(LIB_PATH):

@@ -194,6 +194,8 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
                                             hipMemcpyDeviceToDevice, s));
         return VITA_OK;
     }
+    if (f.sync)     // per-launch path on a workspace that could hold a persistent solve's state: its status word reads "completed"
+        VITA_CHECK_HIP(hipMemsetAsync(reinterpret_cast<char*>(f.sync) + ode_persistent_status_offset(), 0, 128, s));
     const float* src = x0;
     int64_t lds = ldx0;
     for (int k = 0; k < K; ++k) {

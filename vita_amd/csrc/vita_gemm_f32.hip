@@ -487,6 +487,21 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
         VITA_TRY_RC(gemm_f32_via_bf16(a, stream, &taken));
         if (taken) return VITA_OK;
     }
+    if (!a.a_col && a.b_col && wt_cache().n > 0 && a.M >= kWtMinRows) {
+        // dX = dY . W with W^T registered for this step (WtScope): an ordinary row-operand GEMM on the LDS-DMA kernels
+        const WtCache& c = wt_cache();
+        for (int i = 0; i < c.n; ++i) {
+            if (c.e[i].w != a.W || c.e[i].in_f != a.N || c.e[i].out_f != a.K || a.ldw != a.N) continue;
+            vita_linear_args b = a;
+            b.W = c.e[i].wt; b.ldw = a.K; b.b_col = 0;
+            if (!gemm_f32_dma_eligible(b)) break;
+            VITA_TRY_RC(gemm_f32_t_check(a));
+            const SplitK sk = plan_splitk(b);
+            VITA_TRY_RC(gemm_f32_dma(b, stream, sk.splits > 1 ? &sk : nullptr));
+            if (sk.splits > 1) return launch_splitk_reduce(epi_of(b), sk.partial, sk.ld_partial, sk.splits, stream);
+            return VITA_OK;
+        }
+    }
     if (a.a_col || a.b_col) {
         if (!a.a_col && gemm_f32_small_eligible(a, small_ws_ok(a))) {
             VITA_TRY_RC(gemm_f32_t_check(a));

@@ -125,6 +125,8 @@ static int launch_dma(const GemmParamsDma& p0, hipStream_t stream) {
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (ln ? 2 * (size_t)p.K + 2 * BM : 0) + (p.epi.ln_stats ? 2 * BM : 0)) * sizeof(float);
     dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1))), block(DNT);
     if (ln) hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, true, OCC, false, KG>), grid, block, lds, stream, p);
+    else if (p.epi.act_grad_z != nullptr)   // input-gradient GEMM on transposed weights: epilogue multiplies by act'(z)
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC, false, KG, true>), grid, block, lds, stream, p);
     else hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC, false, KG>), grid, block, lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;

@@ -76,6 +76,28 @@ struct Bf16Scope {
     Bf16Scope(void* p, size_t n, int mode) : saved(bf16_stage()) { bf16_stage().ptr = p; bf16_stage().bytes = n; bf16_stage().mode = mode; }
     ~Bf16Scope() { bf16_stage() = saved; }
 };
+// Transposed copies of weights for the input-gradient GEMMs of a large-batch training step: dX = dY . W with W (out, in)
+// contracts over W's ROWS (a column operand, register-staged kernel); with W^T (in, out) materialised once per step it is
+// an ordinary row-operand GEMM and takes the LDS-DMA kernels of the forward pass.  Inside the scope gemm_f32() reroutes
+// every b_col call whose W is registered.  Thread-local like the other scopes.
+struct WtEntry { const float* w; const float* wt; int out_f, in_f; };
+struct WtCache { WtEntry e[80]; int n = 0; };
+inline WtCache& wt_cache() {
+    static thread_local WtCache c;
+    return c;
+}
+struct WtScope {
+    int saved;
+    WtScope() : saved(wt_cache().n) {}
+    ~WtScope() { wt_cache().n = saved; }
+    void add(const float* w, const float* wt, int out_f, int in_f) {
+        WtCache& c = wt_cache();
+        if (c.n < 80) c.e[c.n++] = WtEntry{w, wt, out_f, in_f};
+    }
+};
+constexpr int kWtMinRows = 1024;     // batch from which the step keeps transposed weights
+int launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t s);   // (rows, cols) -> (cols, rows), contiguous
+
 constexpr double kBf16MinFlops = 2147483648.0;   // 2^31: below this the two staging launches cost more than the MFMA rate gains
 constexpr size_t kSplitkBytes = size_t(32) << 20;   // == vita_splitk_workspace_bytes()
 

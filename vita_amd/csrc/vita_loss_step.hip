@@ -398,7 +398,8 @@ int flow_eval_bwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, flo
 }
 
 // One wgrad GEMM + one column-sum per weight over the E*B stacked rows.
-int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs_part) {
+// layer_ready: NULL, or L events; entry l is recorded when layers.l.mlp.{fc1,fc2}.{weight,bias} gradients are final
+int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs_part, void* const* layer_ready = nullptr) {
     const vita_flownet_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, L = w->L, R = c.E * c.B;
     VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
@@ -410,6 +411,7 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
         VITA_TRY(vita_colsum_f32(c.Y2(l, 0), H, R, H, cs_part, mut(g.fc2_b[l]), 0, c.st));
         VITA_TRY(gemm_f32(wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
         VITA_TRY(vita_colsum_f32(c.U(l, 0), FF, R, FF, cs_part, mut(g.fc1_b[l]), 0, c.st));
+        if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
     }
     VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
     VITA_TRY(vita_colsum_f32(c.f.DH0, H, R, H, cs_part, mut(g.in_b), 0, c.st));
@@ -455,7 +457,63 @@ constexpr int kSideMaxRows = 1024;
 // ------------------------------------------------------------------------------------------------
 // whole-step workspace
 // ------------------------------------------------------------------------------------------------
+// every weight whose input-gradient GEMM dX = dY . W runs over >= kWtMinRows rows in a large-batch step: fn(W, out_f, in_f)
+template <class F>
+static void for_each_dgrad_weight(const vita_flownet_weights* fl, const vita_meanflow_weights* mf, const vita_decoder_weights& dec,
+                                  const vita_encoder_weights& enc, F fn) {
+    if (fl) {
+        fn(fl->in_w, fl->H, fl->D);
+        fn(fl->te3_w, fl->H, 4 * fl->TE);
+        for (int l = 0; l < fl->L; ++l) {
+            fn(fl->fc1_w[l], fl->FF, fl->H);
+            fn(fl->fc2_w[l], fl->H, fl->FF);
+            fn(fl->mod_w[l], 3 * fl->H, fl->H);
+        }
+        fn(fl->out_w, fl->D, fl->H);
+    }
+    if (mf) {
+        fn(mf->in_w, mf->H, mf->D);
+        for (int l = 0; l < mf->L; ++l) {
+            fn(mf->fc1_w[l], mf->FF, mf->H);
+            fn(mf->fc2_w[l], mf->H, mf->FF);
+        }
+        fn(mf->u_w, mf->D, mf->H);
+        if (mf->v_w) fn(mf->v_w, mf->D, mf->H);
+    }
+    fn(dec.in_w, dec.HD, dec.D);
+    for (int i = 0; i < dec.NL; ++i) {
+        fn(dec.fc1_w[i], dec.HD, dec.HD);
+        fn(dec.fc2_w[i], dec.HD, dec.HD);
+    }
+    fn(dec.out_w, dec.OUT, dec.HD);
+    if (enc.kind == VITA_ENC_CNN) {
+        for (int i = 1; i < enc.NL; ++i) fn(enc.w1[i], enc.C, enc.C * 5);
+        fn(enc.proj_w, enc.D * (enc.variational ? 2 : 1), enc.C * (enc.T >> enc.NL));
+    }
+}
+static size_t wt_floats(const vita_flownet_weights* fl, const vita_meanflow_weights* mf, const vita_decoder_weights& dec,
+                        const vita_encoder_weights& enc) {
+    size_t n = 0;
+    for_each_dgrad_weight(fl, mf, dec, enc, [&](const float*, int o, int i) { n += (((size_t)o * i) + 63) & ~size_t(63); });
+    return n;
+}
+// transposes every such weight into `buf` (stream-ordered, once per step) and registers the copies with the scope
+static int stage_wt(WtScope& sc, float* buf, const vita_flownet_weights* fl, const vita_meanflow_weights* mf, const vita_decoder_weights& dec,
+                    const vita_encoder_weights& enc, hipStream_t st) {
+    int rc = VITA_OK;
+    size_t off = 0;
+    for_each_dgrad_weight(fl, mf, dec, enc, [&](const float* w, int o, int i) {
+        float* dst = buf + off;
+        off += (((size_t)o * i) + 63) & ~size_t(63);
+        if (rc != VITA_OK || w == nullptr) return;
+        rc = launch_transpose_f32(w, o, i, dst, st);
+        sc.add(w, dst, o, i);
+    });
+    return rc;
+}
+
 struct StepWs {
+    float* wt;                        // transposed weights of the input-gradient GEMMs (train, B >= kWtMinRows)
     float *sk, *consts, *loss_part, *cs_part;
     float *sk_side[3], *cs_side[3];   // split-K / column-sum scratch of the side-stream branches
     float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
@@ -537,6 +595,7 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
         s.stage_bytes = bf16_stage_bytes(w, B, K);
         s.stage = c.take(s.stage_bytes / sizeof(float));
     }
+    s.wt = (train && B >= (size_t)kWtMinRows) ? c.take(wt_floats(&w.flow, nullptr, w.dec, w.enc)) : nullptr;
     s.flow = carve_flow_train(c, w.flow, B, K, train);
     s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
@@ -666,6 +725,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     FlowCtx fc{&w->flow, s.flow, B, K, 1 + K, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
     Bf16Scope bfscope(s.stage, s.stage_bytes, cfg->gemm_bf16);
+    WtScope wtscope;
+    if (s.wt) VITA_TRY(stage_wt(wtscope, s.wt, &w->flow, nullptr, w->dec, w->enc, st));
     // the bf16 staging region is reused call after call in stream order: one stream only in that mode
     Side* side = (train && B <= kSideMaxRows && cfg->gemm_bf16 == 0 && cfg->side_streams != 0) ? side_for_current_device() : nullptr;
     const bool vae = w->enc.variational != 0;
@@ -747,6 +808,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         if (grad_ready && grad_ready[i]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)grad_ready[i], st));
         return VITA_OK;
     };
+    void* const* layer_ready = (grad_ready && cfg->grad_ready_layers) ? grad_ready + 3 : nullptr;
     // decoder: dZZ = d loss / d [pred; z1] through the reconstruction terms
     if (!dec_pred) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ, 0, (size_t)B * D * 4, st));
     if (!dec_enc) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ + (size_t)B * D, 0, (size_t)B * D * 4, st));
@@ -853,13 +915,13 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
             VITA_TRY(encoders_bwd(s.cs_side[2], side->s[2]));
             VITA_CHECK_HIP(hipEventRecord(side->join[2], side->s[2]));
         }
-        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready));
         VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
         VITA_TRY(record(1));
         VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[2], 0));
         if (dec_on_side) VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[0], 0));
     } else {
-        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready));
         VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
         VITA_TRY(record(1));
         VITA_TRY(encoders_bwd(s.cs_part, st));
@@ -1103,6 +1165,7 @@ inline unsigned mfgrid(int64_t n) {
 }
 
 struct MfTrainWs {
+    float* wt;                                                      // transposed weights (B >= kWtMinRows), see StepWs
     float *sk, *consts, *loss_part, *cs_part;
     float *tv, *hv, *ones, *At, *St, *Ah, *Sh, *tc;              // conditioning rows T = B + K
     float *dAt, *dSt, *dtc_tan;                                    // tangent of the conditioning (B rows)
@@ -1131,6 +1194,7 @@ MfTrainWs carve_mf_train(void* ws, const vita_meanflow_policy_weights& w, const 
     // improved MeanFlow: one more (forward-only) evaluation slot and B more conditioning rows
     const size_t K = (cfg.decode_flow_latents && !cfg.freeze_encoder && !cfg.freeze_decoder) ? (size_t)cfg.num_steps : 0, imf = cfg.use_imf ? 1 : 0, T = B + K + imf * B, E = 1 + K + imf;
     const size_t D = w.flow.D, H = w.flow.H, FF = w.flow.FF, L = w.flow.L;
+    s.wt = B >= (size_t)kWtMinRows ? c.take(wt_floats(nullptr, &w.flow, w.dec, w.enc)) : nullptr;
     s.sk = c.take(kSplitkBytes / sizeof(float));
     s.consts = c.take(16);
     s.loss_part = c.take((size_t)vita_loss_partials_count());
@@ -1265,8 +1329,8 @@ size_t vita_compute_loss_meanflow_workspace_bytes(const vita_meanflow_policy_wei
 int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const vita_meanflow_policy_weights* grads,
                                    const vita_meanflow_loss_config* cfg, const float* obs_features, int64_t ldobs, const float* actions,
                                    const float* t, const float* r, const float* enc_noise, int32_t B, float* losses,
-                                   float* d_obs_features, int64_t ld_dobs, void* workspace, size_t workspace_bytes,
-                                   vita_stream_t stream) {
+                                   float* d_obs_features, int64_t ld_dobs, void* const* grad_ready, void* workspace,
+                                   size_t workspace_bytes, vita_stream_t stream) {
     const char* who = "vita_compute_loss_meanflow_f32";
     VITA_REQUIRE(d_obs_features == nullptr || (grads != nullptr && w != nullptr && ld_dobs >= w->O), "%s: d_obs_features needs grads and ld_dobs >= O", who);
     VITA_REQUIRE(w && cfg, "%s: null weights / config", who);
@@ -1317,6 +1381,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     float* z1 = s.ZZ + (size_t)B * D;
     MfCtx mc{fw, &s, B, E, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
+    WtScope wtscope;
+    if (s.wt && grads) VITA_TRY(stage_wt(wtscope, s.wt, nullptr, &w->flow, w->dec, w->enc, st));
     const float seeds[6] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight, cfg->enc_contrastive_weight,
                             cfg->flow_contrastive_weight};
     VITA_TRY(launch_set_scalars(s.consts, seeds, 6, st));
@@ -1477,6 +1543,11 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_w), 0, (size_t)gd.OUT * gd.TR * 4, st));
         VITA_CHECK_HIP(hipMemsetAsync(mut(gd.out_b), 0, (size_t)gd.OUT * 4, st));
     }
+    auto record = [&](int i) -> int {      // as in vita_compute_loss_f32: 0 decoder, 1 flow net, 2 everything
+        if (grad_ready && grad_ready[i]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)grad_ready[i], st));
+        return VITA_OK;
+    };
+    VITA_TRY(record(0));
     float* dpred = s.dZZ;
     float* dz1 = s.dZZ + (size_t)B * D;
     if (do_cons) VITA_TRY(vita_mse_loss_bwd_f32(pred, z1, (int64_t)B * D, s.consts + 1, dpred, dz1, 1, st));
@@ -1551,6 +1622,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
             VITA_TRY(vita_colsum_f32(s.dA1, H, Tc, H, s.cs_part, mut(b.gb1), 0, st));
         }
     }
+    VITA_TRY(record(1));
     // encoders
     {
         StepWs es{};
@@ -1570,6 +1642,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     VITA_TRY(vita_colsum_f32(s.dz0, D, B, D, s.cs_part, mut(g.obs_b), 0, st));
     // what flows on into a trainable observer (vita_policy.py:113-114): d obs_features = d z0 . obs_w
     if (d_obs_features) VITA_TRY(gemm_f32(dgrad(s.dz0, D, w->obs_w, w->O, d_obs_features, ld_dobs, B, w->O, D), st));
+    VITA_TRY(record(2));
     return VITA_OK;
 }
 

@@ -244,6 +244,25 @@ __global__ __launch_bounds__(TT) void nlc_ncl_kernel(const float* __restrict__ i
     }
 }
 
+// (rows, cols) -> (cols, rows), both contiguous: 32 x 32 tiles through LDS, both sides coalesced (weight transposes of the
+// large-batch training step, vita_host.h WtScope)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int r = r0 + ty + i, c = c0 + tx;
+        if (r < rows && c < cols) tile[ty + i][tx] = src[(int64_t)r * cols + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 32; i += 8) {
+        const int c = c0 + ty + i, r = r0 + tx;
+        if (r < rows && c < cols) dst[(int64_t)c * rows + r] = tile[tx][ty + i];
+    }
+}
+
 // ---- CFM interpolation backward --------------------------------------------------------------------
 // xt = t*x1[j] + (1-t)*x0[i], ut = x1[j]-x0[i]  =>  dx0[i] += (1-t)*dxt - dut ; dx1[j] += t*dxt + dut
 __global__ __launch_bounds__(TT) void cfm_bwd_kernel(const float* __restrict__ dxt, const float* __restrict__ dut, const float* __restrict__ t,
@@ -380,6 +399,15 @@ int launch_weighted_sum(const float* vals, const float* host_w, int n, float* ou
 using namespace vita;
 
 #define LAUNCH_OK() do { VITA_CHECK_HIP(hipGetLastError()); return VITA_OK; } while (0)
+
+namespace vita {
+int launch_transpose_f32(const float* src, int rows, int cols, float* dst, hipStream_t s) {
+    VITA_REQUIRE(src && dst && rows > 0 && cols > 0, "transpose: bad arguments");
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, src, dst, rows, cols);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+}  // namespace vita
 
 extern "C" {
 

@@ -880,6 +880,20 @@ def loss_config(num_steps: int = 6, recon: str = "l1", decode_flow_latents: bool
     return c
 
 
+def _event_handles(events, who: str):
+    """torch.cuda.Event list -> C array of hipEvent_t (None entries stay NULL), or None."""
+    if events is None:
+        return None
+    handles = []
+    for e in events:
+        h = e.cuda_event if e is not None else None
+        if e is not None and not h:
+            raise L.VitaHipError(f"{who}: grad_ready event has no hipEvent_t yet (torch creates it on the first "
+                                 "record(): call event.record() once before passing it)")
+        handles.append(h)
+    return (L.c_fp * len(handles))(*handles)
+
+
 def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, *, grads: Optional[PolicyHandle] = None,
                  pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None,
                  enc_noise: Optional[Tensor] = None, fm_noise: Optional[Tensor] = None):
@@ -910,16 +924,12 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
     elif losses.numel() < L.LOSS_COUNT:
         raise L.VitaHipError(f"compute_loss: losses needs {L.LOSS_COUNT} floats")
     dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
-    ev = None
-    if grad_ready_events is not None:
-        handles = []
-        for e in grad_ready_events:
-            h = e.cuda_event if e is not None else None
-            if e is not None and not h:
-                raise L.VitaHipError("compute_loss: grad_ready event has no hipEvent_t yet (torch creates it on the first "
-                                     "record(): call event.record() once before passing it)")
-            handles.append(h)
-        ev = (L.c_fp * 3)(*handles)
+    ev = _event_handles(grad_ready_events, "compute_loss")
+    if ev is not None and len(ev) > 3:      # 3 + L events: per-layer readiness of the flow net's fc1 / fc2 gradients
+        if len(ev) != 3 + pw.w.flow.L:
+            raise L.VitaHipError(f"compute_loss: {len(ev)} grad_ready events; pass 3, or 3 + L = {3 + pw.w.flow.L}")
+        cfg = L.LossConfig.from_buffer_copy(cfg)
+        cfg.grad_ready_layers = 1
     nbytes = lib.vita_compute_loss_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
     ws = workspace(dev, nbytes)
     L.check(lib.vita_compute_loss_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
@@ -976,7 +986,7 @@ def meanflow_loss_config(num_steps: int = 1, recon: str = "l1", decode_flow_late
 
 def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, r: Tensor, *,
                           grads: Optional[MeanFlowPolicyHandle] = None, losses: Optional[Tensor] = None,
-                          enc_noise: Optional[Tensor] = None, need_dobs: bool = False):
+                          enc_noise: Optional[Tensor] = None, need_dobs: bool = False, grad_ready_events=None):
     """VitaPolicy.compute_loss with the MeanFlow matcher (+ backward when `grads` is given): vita_compute_loss_meanflow_f32.
     Returns losses (16,) indexed as _lib.MF_LOSS_NAMES (index 1 = meanflow_loss, or imf_loss + w * aux_v_loss); with need_dobs
     (and grads) the pair (losses, d loss / d obs_features).  No host sync."""
@@ -1009,6 +1019,7 @@ def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, a
                                                obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(), r.data_ptr(),
                                                enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
                                                dobs.data_ptr() if dobs is not None else None, _ld(dobs) if dobs is not None else 0,
+                                               _event_handles(grad_ready_events[:3] if grad_ready_events else None, "compute_loss_meanflow"),
                                                ws.data_ptr(), ws.numel(), _stream(obs_features)),
             "vita_compute_loss_meanflow_f32")
     return (losses, dobs) if need_dobs else losses

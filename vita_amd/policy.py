@@ -387,6 +387,34 @@ class VitaPolicy(nn.Module):
             off += n
         return out
 
+    def reduce_plan(self):
+        """[(lo, hi, event)] over the flat gradient buffer, in the order the events fire inside the fused backward: the
+        decoder (event 0); then, for the default flow net, each layer's mlp.fc1 / mlp.fc2 gradients (event 3 + l: their
+        stacked weight-gradient GEMMs run layer by layer, vita_loss_config.grad_ready_layers); the rest of the flow net
+        (event 1: input / output projections, norm, time path, modulators); the encoders (event 2).  The MeanFlow step
+        records events 0..2 only."""
+        plan, off = [], 0
+        named = self.hot_path_named_parameters()
+        for k, p in named:
+            n = p.numel()
+            if k.startswith("action_decoder."):
+                ev = 0
+            elif k.startswith("flow_net."):
+                ev = 1
+                parts = k.split(".")
+                if not self.mean_flow and parts[1] == "layers" and parts[3] == "mlp":
+                    ev = 3 + int(parts[2])
+            else:
+                ev = 2
+            if plan and plan[-1][2] == ev and plan[-1][1] == off:
+                plan[-1] = (plan[-1][0], off + n, ev)
+            else:
+                plan.append((off, off + n, ev))
+            off += n
+        order = {0: 0, 1: 10 ** 6, 2: 10 ** 6 + 1}
+        plan.sort(key=lambda seg: (order.get(seg[2], seg[2]), seg[0]))
+        return plan
+
     def flatten_parameters(self):
         """Re-home the hot-path parameters (and their .grad) as views of two flat fp32 device buffers, so the data-parallel
         trainer all-reduces contiguous buckets and the optimizer is one fused kernel.  Call after .to(device)."""
@@ -526,12 +554,8 @@ class VitaPolicy(nn.Module):
                 enc_noise = torch.randn(obs_features.shape[0], self.latent_dim, device=obs_features.device)
             elif not self.use_action_vae or not self.training:
                 enc_noise = None
-            out = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r.to(torch.float32), grads=gw, losses=losses,
-                                            enc_noise=enc_noise)
-            for e in (grad_ready_events or ()):     # the MeanFlow step records no intermediate events: every bucket is ready at its end
-                if e is not None:
-                    e.record(torch.cuda.current_stream(obs_features.device))
-            return out
+            return ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r.to(torch.float32), grads=gw, losses=losses,
+                                             enc_noise=enc_noise, grad_ready_events=grad_ready_events)
         t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
                                                             actions, enc_noise, fm_noise)
         out, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,

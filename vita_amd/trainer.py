@@ -40,11 +40,12 @@ class PolicyTrainer:
         self.ema = self.flat.clone() if config.use_ema else None                    # base_policy.py:45-49
         self.rank, self.world = world_info(group)
         self.update_ranges = policy.trainable_ranges()    # frozen modules are skipped by the optimizer, as torch skips grad=None
-        self.reducer = BucketReducer(self.flat_grad, policy.bucket_ranges, group, max_bucket_elems)
+        self.plan = policy.reduce_plan()              # [(lo, hi, event index)] in the order the backward makes them final
+        self.reducer = BucketReducer(self.flat_grad, [(lo, hi) for lo, hi, _ in self.plan], group, max_bucket_elems)
         self.overlap = overlap
         self.events = None
         if self.world > 1:
-            self.events = [torch.cuda.Event() for _ in range(3)]
+            self.events = [torch.cuda.Event() for _ in range(1 + max(ev for _, _, ev in self.plan))]
             for e in self.events:   # torch creates the hipEvent_t lazily, on the first record: the C side needs the handle
                 e.record(torch.cuda.current_stream(self.device))
         self.num_training_steps = num_training_steps or config.train.steps
@@ -77,8 +78,8 @@ class PolicyTrainer:
         batch = net.normalize_targets(batch)
         net.loss_and_grads(batch, t=t, pair_i=pair_i, pair_j=pair_j, grad_ready_events=self.events if self.overlap else None,
                            losses=self.losses)
-        for i in range(len(self.reducer.segments)):
-            self.reducer.reduce(i, self.events[i] if (self.events and self.overlap) else None)
+        for i, (_, _, ev) in enumerate(self.plan):
+            self.reducer.reduce(i, self.events[ev] if (self.events and self.overlap) else None)
         scale = self.reducer.finish()
         ops.sumsq(self.flat_grad, out=self.gnorm_sq)
         step = self.step_counter + 1
