@@ -17,10 +17,18 @@ x0 = torch.randn(B, 512, generator=torch.Generator().manual_seed(1)).to(dev)
 PH = 2 + 2 * L
 buf = torch.zeros(256 * K * PH * 6, dtype=torch.int64, device=dev)
 lib = _lib.load()
+BF16 = len(sys.argv) > 1 and sys.argv[1] == "bf16"
+if BF16:
+    dw, bw = ops.DecoderHandle(sd, dev), ops.Bf16Weights(sd, dev)
+    obs = torch.randn(B, 533, generator=torch.Generator().manual_seed(2)).to(dev)
+    ob = sd["obs_encoder.bias"].to(dev)
+    run = lambda: ops.generate_actions_bf16(ob, fw, dw, bw, obs, K)   # noqa: E731
+else:
+    run = lambda: ops.ode_sample(fw, x0, K)   # noqa: E731
 for _ in range(3):
-    ops.ode_sample(fw, x0, K)
+    run()
 lib.vita_debug_ode_stamps(buf.data_ptr())
-ops.ode_sample(fw, x0, K)
+run()
 torch.cuda.synchronize()
 lib.vita_debug_ode_stamps(None)
 raw = buf.cpu().view(256, K * PH, 6).double()

@@ -4,6 +4,8 @@
 // produced in bf16 by the kernel that computes it (LayerNorm kernel, GEMM epilogues), so nothing is converted twice.
 // v_mfma_f32_32x32x16_bf16 runs at 16x the fp32 MFMA rate, which moves these GEMMs from MFMA-bound to LDS/HBM-bound.
 // Stated tolerance vs the fp32 reference: see tests/test_gpu_bf16.py.
+#include <stdlib.h>
+
 #include "vita_host.h"
 
 namespace vita {
@@ -21,8 +23,15 @@ static vita_linear_args lin_bf16(const uint16_t* X, int64_t ldx, const uint16_t*
 struct FlowWsB {
     float *ts, *sin, *hid, *silu, *mod, *h;
     uint16_t *hnb, *ub, *xb0, *xb1;
+    float *stat, *c1, *c2, *c1f, *c2f;   // LayerNorm folded into the GEMM epilogues (as in vita_api.hip), tables from the bf16 weights
+    float* sync;                         // hand-off state + phase table of the persistent launch (vita_ode_persistent.hip)
     size_t bytes;
 };
+// the fold needs interior 128 x 128 tiles; VITA_NO_LN_FOLD=1 keeps the LayerNorm kernels
+static bool use_ln_fold_b(const vita_flownet_weights* w, int B) {
+    static const bool off = getenv("VITA_NO_LN_FOLD") != nullptr && atoi(getenv("VITA_NO_LN_FOLD")) != 0;
+    return !off && B >= 1024 && B % 128 == 0 && w->L >= 1 && w->H % 128 == 0 && w->H <= 2048 && w->FF % 128 == 0 && w->D % 128 == 0;
+}
 static uint16_t* take16(Carver& c, size_t n) { return reinterpret_cast<uint16_t*>(c.take((n + 1) / 2)); }
 static FlowWsB carve_flow_b(void* ws, const vita_flownet_weights* w, int B, int T) {
     Carver c(ws);
@@ -37,6 +46,15 @@ static FlowWsB carve_flow_b(void* ws, const vita_flownet_weights* w, int B, int 
     f.ub = take16(c, (size_t)B * r8(w->FF));
     f.xb0 = take16(c, (size_t)B * r8(w->D));
     f.xb1 = take16(c, (size_t)B * r8(w->D));
+    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = f.sync = nullptr;
+    if (use_ln_fold_b(w, B)) {
+        f.sync = c.take(ode_persistent_sync_bytes(T, w->L) / sizeof(float));
+        f.stat = c.take((size_t)(w->H / 128) * B * 2);
+        f.c1 = c.take((size_t)T * w->L * w->FF);
+        f.c2 = c.take((size_t)T * w->L * w->FF);
+        f.c1f = c.take((size_t)w->D);
+        f.c2f = c.take((size_t)w->D);
+    }
     f.bytes = c.off;
     return f;
 }
@@ -80,6 +98,36 @@ static int flow_step_b(const vita_flownet_weights* w, const vita_bf16_weights* b
     return gemm_bf16_dma(o, xb_out, Dp, s);
 }
 
+// flow_step_b with the LayerNorms folded (vita_api.hip: flow_eval_folded): the producer of h also writes bf16(h * (1 + scale)) (or
+// h * norm_w) and per-tile row statistics, the consumer finishes the normalisation on its accumulators; k indexes the c-tables.
+static int flow_step_b_folded(const vita_flownet_weights* w, const vita_bf16_weights* bw, const FlowWsB& f, const float* x, int64_t ldx,
+                              const uint16_t* xb, const float* mod, int k, float* x_out, int64_t ldo, uint16_t* xb_out, float dt, int B,
+                              hipStream_t s) {
+    const int D = w->D, H = w->H, FF = w->FF, L = w->L, nseg = H / 128;
+    auto producer = [&](const vita_linear_args& a, const float* next_mul, int add_one) -> int {
+        EpiFold e;
+        e.aux_bf = f.hnb; e.ld_aux_bf = H; e.aux_mul = next_mul; e.aux_add_one = add_one; e.stat_out = f.stat;
+        return gemm_bf16_dma(a, nullptr, 0, s, nullptr, &e);
+    };
+    VITA_TRY(producer(lin_bf16(xb, D, bw->in_w, D, w->in_b, f.h, H, B, H, D, VITA_ACT_NONE), mod + H, 1));
+    for (int l = 0; l < L; ++l) {
+        const float* gamma = mod + (size_t)l * 3 * H;
+        EpiFold c;
+        c.ln_stats = f.stat; c.ln_c1 = f.c1 + ((size_t)k * L + l) * FF; c.ln_nseg = nseg; c.ln_fold_eps = 1e-6f;
+        VITA_TRY(gemm_bf16_dma(lin_bf16(f.hnb, H, bw->fc1_w[l], H, f.c2 + ((size_t)k * L + l) * FF, nullptr, 0, B, FF, H, VITA_ACT_GELU_TANH),
+                               f.ub, FF, s, nullptr, &c));
+        vita_linear_args b = lin_bf16(f.ub, FF, bw->fc2_w[l], FF, w->fc2_b[l], f.h, H, B, H, FF, VITA_ACT_NONE);
+        b.gate = gamma; b.ld_gate = 0; b.resid = f.h; b.ld_resid = H;
+        if (l + 1 < L) VITA_TRY(producer(b, mod + (size_t)(l + 1) * 3 * H + H, 1));
+        else VITA_TRY(producer(b, w->norm_w, 0));
+    }
+    vita_linear_args o = lin_bf16(f.hnb, H, bw->out_w, H, f.c2f, x_out, ldo, B, D, H, VITA_ACT_NONE);
+    o.use_gate_scalar = 1; o.gate_scalar = dt; o.resid = x; o.ld_resid = ldx;
+    EpiFold c;
+    c.ln_stats = f.stat; c.ln_c1 = f.c1f; c.ln_nseg = nseg; c.ln_fold_eps = 1e-5f;
+    return gemm_bf16_dma(o, xb_out, D, s, nullptr, &c);
+}
+
 // Columns D..r8(D)-1 of the bf16 state must be zero for the next in_proj: they are, because the packers zero-fill and
 // an epilogue never writes past N = D (the workspace is zeroed once per call when D % 8 != 0).
 static int ode_sample_b(const vita_flownet_weights* w, const vita_bf16_weights* bw, const float* x0, int64_t ldx0, const uint16_t* x0b,
@@ -90,13 +138,19 @@ static int ode_sample_b(const vita_flownet_weights* w, const vita_bf16_weights* 
         VITA_CHECK_HIP(hipMemsetAsync(f.hnb, 0, (size_t)((char*)ws + f.bytes - (char*)f.hnb), s));
     VITA_TRY(launch_step_times(f.ts, K, s));
     VITA_TRY(time_path_b(w, f, K, s));
+    const bool fold = f.stat != nullptr;
+    if (fold) VITA_TRY(launch_ln_fold_tables_all(w, f.mod, K, f.c1, f.c2, f.c1f, f.c2f, s, bw));
     const float dt = (float)(1.0 / (double)K);
+    if (fold && ode_persistent_eligible(w, B, x0, ldx0, x_out, ldo))      // all K steps in one persistent launch
+        return launch_ode_persistent_bf16(w, bw, x0, ldx0, x0b, x_out, ldo, f.xb0, xb_final, B, K, dt, f.h, f.hnb, f.ub, f.stat, f.mod, f.c1,
+                                          f.c2, f.c1f, f.c2f, f.sync, s);
     const float* src = x0;
     int64_t lds = ldx0;
     const uint16_t* srcb = x0b;
     for (int k = 0; k < K; ++k) {
         uint16_t* dstb = (k == K - 1 && xb_final) ? xb_final : ((k & 1) ? f.xb1 : f.xb0);
-        VITA_TRY(flow_step_b(w, bw, f, src, lds, srcb, f.mod + (size_t)k * L * 3 * H, x_out, ldo, dstb, dt, B, s));
+        if (fold) VITA_TRY(flow_step_b_folded(w, bw, f, src, lds, srcb, f.mod + (size_t)k * L * 3 * H, k, x_out, ldo, dstb, dt, B, s));
+        else VITA_TRY(flow_step_b(w, bw, f, src, lds, srcb, f.mod + (size_t)k * L * 3 * H, x_out, ldo, dstb, dt, B, s));
         src = x_out; lds = ldo; srcb = dstb;
     }
     return VITA_OK;

@@ -340,7 +340,8 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
 // One wave per weight row j of one "layer" (blockIdx.y): rs = sum_i W[j][i]; for each of the K modulation vectors
 // c1[k][j] = sum_i mul_k[i] W[j][i] (+ rs), c2[k][j] = sum_i add_k[i] W[j][i] + bias[j].  The weight row stays in registers
 // (H <= 2048), the per-lane partial dot products of 4 vectors are formed before their reductions.  Deterministic.
-struct FoldTableJob { const float* W; const float* bias; const float* mul; const float* add; float* c1; float* c2; int N; int K; int add_one; int64_t ld_vec, ld_c; };
+struct FoldTableJob { const float* W; const float* bias; const float* mul; const float* add; float* c1; float* c2; int N; int K; int add_one; int64_t ld_vec, ld_c;
+                      const uint16_t* Wb; int64_t ldwb; };   // Wb != NULL: the weight rows are bf16 (row stride ldwb): the bf16-operand sampler's tables
 struct FoldTableJobs { FoldTableJob j[VITA_MAX_LAYERS + 1]; };
 
 __global__ __launch_bounds__(256) void ln_fold_tables_kernel(FoldTableJobs jobs, int H) {
@@ -355,7 +356,15 @@ __global__ __launch_bounds__(256) void ln_fold_tables_kernel(FoldTableJobs jobs,
     for (int c = 0; c < 8; ++c) {
         w[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int i = (c * 64 + lane) * 4;
-        if (c < nch && i < H) w[c] = *reinterpret_cast<const f32x4*>(wr + i);
+        if (c < nch && i < H) {
+            if (jb.Wb) {
+                const u16x4 wb = *reinterpret_cast<const u16x4*>(jb.Wb + (int64_t)j * jb.ldwb + i);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) w[c][e] = bf16_to_f32(wb[e]);
+            } else {
+                w[c] = *reinterpret_cast<const f32x4*>(wr + i);
+            }
+        }
         rs += (w[c][0] + w[c][1]) + (w[c][2] + w[c][3]);
     }
     rs = wave_sum(rs);
@@ -391,17 +400,20 @@ __global__ __launch_bounds__(256) void ln_fold_tables_kernel(FoldTableJobs jobs,
 }
 
 // all layers' fc1 tables + the final (norm -> out_proj) table in one launch.  H % 4 == 0, 16-byte aligned rows.
-int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s) {
+int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s,
+                              const vita_bf16_weights* bw) {
     const int H = w->H, FF = w->FF, L = w->L;
     VITA_REQUIRE(H <= 2048 && H % 4 == 0, "ln_fold_tables: H=%d out of range", H);
     FoldTableJobs jobs{};
     int nmax = w->D;
     for (int l = 0; l < L; ++l) {
         jobs.j[l] = FoldTableJob{w->fc1_w[l], w->fc1_b[l], mod + (size_t)l * 3 * H + H, mod + (size_t)l * 3 * H + 2 * H,
-                                 c1 + (size_t)l * FF, c2 + (size_t)l * FF, FF, T, 1, (int64_t)L * 3 * H, (int64_t)L * FF};
+                                 c1 + (size_t)l * FF, c2 + (size_t)l * FF, FF, T, 1, (int64_t)L * 3 * H, (int64_t)L * FF,
+                                 bw ? bw->fc1_w[l] : nullptr, (int64_t)((H + 7) & ~7)};
         if (FF > nmax) nmax = FF;
     }
-    jobs.j[L] = FoldTableJob{w->out_w, w->out_b, w->norm_w, w->norm_b, c1f, c2f, w->D, 1, 0, 0, (int64_t)w->D};
+    jobs.j[L] = FoldTableJob{w->out_w, w->out_b, w->norm_w, w->norm_b, c1f, c2f, w->D, 1, 0, 0, (int64_t)w->D,
+                             bw ? bw->out_w : nullptr, (int64_t)((H + 7) & ~7)};
     hipLaunchKernelGGL(ln_fold_tables_kernel, dim3((nmax + 3) / 4, L + 1), dim3(256), 0, s, jobs, H);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;

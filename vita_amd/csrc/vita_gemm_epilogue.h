@@ -40,6 +40,7 @@ struct EpiParams {
     // producer side: besides Y = h, write aux_out = h * (aux_mul [+ 1]) (the next GEMM's A operand) and, per row and per
     // 128-column tile, (mean, M2) of h over the tile's columns into stat_out[(tile_n * M + row) * 2]
     float* aux_out; int64_t ld_aux; const float* aux_mul; int aux_add_one;
+    uint16_t* aux_bf; int64_t ld_aux_bf;      // the same product as bf16 (the bf16-operand sampler's next A operand); either or both
     float* stat_out;
     // consumer side: acc <- rstd_row * (acc - mean_row * ln_c1[col]) before bias/activation, with (mean, rstd) of the row
     // combined from ln_nseg partials of ln_seg columns each (Chan's formula), rstd = 1/sqrt(M2/H + ln_eps)
@@ -131,6 +132,10 @@ __device__ __forceinline__ void store8_wt(__amdgpu_buffer_rsrc_t r, int64_t elem
     __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)(elem_off * 4), 0, 16);
 }
 
+__device__ __forceinline__ void store8_bf_wt(__amdgpu_buffer_rsrc_t r, int64_t elem_off, const u16x4& v) {   // 4 bf16
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_t, v), r, (int)(elem_off * 2), 0, 16);
+}
+
 template <int BM, int BN, int MI, int NI, int NT_, int ACT, bool BWD, int KG = 1, bool SC1 = false>
 __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float* obuf, const EpiParams& e, int m0, int n0, int wm, int wn,
                                               int lane, int tid, int kg = 0, const float* srow = nullptr) {
@@ -207,12 +212,14 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
             if (e.bias) b = *reinterpret_cast<const f32x4*>(e.bias + col);
             if (gate_vec) gv = *reinterpret_cast<const f32x4*>(e.gate + col);
             f32x4 c1 = {0.f, 0.f, 0.f, 0.f}, am = c1;
-            __amdgpu_buffer_rsrc_t rs_y, rs_aux, rs_stat;
+            __amdgpu_buffer_rsrc_t rs_y, rs_aux, rs_stat, rs_auxb, rs_ybf;
             if constexpr (SC1) {
                 rs_y = wt_rsrc(e.Y); rs_aux = wt_rsrc(e.aux_out); rs_stat = wt_rsrc(e.stat_out);
+                rs_auxb = wt_rsrc(e.aux_bf); rs_ybf = wt_rsrc(e.ybf);
             }
             if (e.ln_stats) c1 = *reinterpret_cast<const f32x4*>(e.ln_c1 + col);
-            if (e.aux_out) {
+            const bool has_aux = e.aux_out != nullptr || e.aux_bf != nullptr;
+            if (has_aux) {
                 am = *reinterpret_cast<const f32x4*>(e.aux_mul + col);
                 if (e.aux_add_one) am = am + 1.0f;
             }
@@ -253,11 +260,22 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                     u16x4 hb;
 #pragma unroll
                     for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(out[k]);
-                    *reinterpret_cast<u16x4*>(e.ybf + row * e.ld_ybf + col) = hb;
+                    if constexpr (SC1) store8_bf_wt(rs_ybf, row * e.ld_ybf + col, hb);
+                    else *reinterpret_cast<u16x4*>(e.ybf + row * e.ld_ybf + col) = hb;
                 }
-                if (e.aux_out) {
-                    if constexpr (SC1) store16_wt(rs_aux, row * e.ld_aux + col, out * am);
-                    else *reinterpret_cast<f32x4*>(e.aux_out + row * e.ld_aux + col) = out * am;
+                if (has_aux) {
+                    const f32x4 hm = out * am;
+                    if (e.aux_out) {
+                        if constexpr (SC1) store16_wt(rs_aux, row * e.ld_aux + col, hm);
+                        else *reinterpret_cast<f32x4*>(e.aux_out + row * e.ld_aux + col) = hm;
+                    }
+                    if (e.aux_bf) {
+                        u16x4 hb;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) hb[k] = f32_to_bf16(hm[k]);
+                        if constexpr (SC1) store8_bf_wt(rs_auxb, row * e.ld_aux_bf + col, hb);
+                        else *reinterpret_cast<u16x4*>(e.aux_bf + row * e.ld_aux_bf + col) = hb;
+                    }
                     if constexpr (C4 == 32) {
                         // a row's BN = 128 outputs sit in 32 consecutive lanes.  (mean, M2) in ONE shuffle chain: sums of
                         // d = x - x0 and d^2 with x0 the row's first element (shifted one-pass: no cancellation against the mean)

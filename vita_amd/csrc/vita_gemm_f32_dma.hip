@@ -90,7 +90,7 @@ static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
     snprintf(g_last_cfg, sizeof(g_last_cfg), "gemm_f32_dma_kernel<%d,%d,%d,%d,bf16>", BM, BN, BK, NS);
     p.tiles_m = (p.M + BM - 1) / BM;
     p.tiles_n = (p.N + BN - 1) / BN;
-    const size_t lds = (size_t)NS * (BM + BN) * BK * sizeof(float);
+    const size_t lds = ((size_t)NS * (BM + BN) * BK + (p.epi.ln_stats ? 2 * BM : 0)) * sizeof(float);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1)));
     if (p.epi.act_grad_z != nullptr)
         hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true, 1, true>), grid, dim3(DNT), lds, stream, p);
@@ -192,7 +192,7 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
 // bf16 operands: a.X / a.W point at bf16 data, a.K / a.ldx / a.ldw count bf16 elements (multiples of 8, 16-byte aligned
 // rows); everything on the output side is as in the fp32 call, plus the optional bf16 copy of Y.
 // sk: split-K plan in the kernel's 4-byte k units (bf16 pairs), or NULL.  act_grad_z: as in the transposed fp32 GEMMs.
-int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk) {
+int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk, const EpiFold* fold) {
     GemmParamsDma p{};
     p.X = a.X; p.ldx = a.ldx / 2; p.W = a.W; p.ldw = a.ldw / 2; p.bias = a.bias;
     p.Y = a.Y; p.ldy = a.ldy; p.M = a.M; p.N = a.N; p.K = a.K / 2;
@@ -204,6 +204,16 @@ int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipS
     p.epi.act_grad_z = a.act_grad_z; p.epi.ld_act_grad_z = a.ld_act_grad_z;
     p.epi.ybf = ybf; p.epi.ld_ybf = ld_ybf;
     p.epi.vec = epi_vec_ok(p.epi);
+    if (fold) {     // LayerNorm folded into the neighbouring GEMMs, as in gemm_f32_dma: interior 128-row / 128-column tiles only
+        auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+        VITA_REQUIRE(p.epi.vec && a.M % 128 == 0 && a.N % 128 == 0 && sk == nullptr && al(fold->aux_out) && al(fold->aux_bf) && al(fold->aux_mul) &&
+                         al(fold->ln_c1) && fold->ld_aux % 4 == 0 && fold->ld_aux_bf % 4 == 0,
+                     "folded LayerNorm epilogue (bf16) needs interior, 16-byte aligned tiles (M=%d N=%d)", a.M, a.N);
+        p.epi.aux_out = fold->aux_out; p.epi.ld_aux = fold->ld_aux; p.epi.aux_bf = fold->aux_bf; p.epi.ld_aux_bf = fold->ld_aux_bf;
+        p.epi.aux_mul = fold->aux_mul; p.epi.aux_add_one = fold->aux_add_one;
+        p.epi.stat_out = fold->stat_out; p.epi.ln_stats = fold->ln_stats; p.epi.ln_c1 = fold->ln_c1; p.epi.ln_nseg = fold->ln_nseg;
+        p.epi.ln_fold_eps = fold->ln_fold_eps;
+    }
     if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (t128 >= 512) return launch_dma_bf16<128, 128, 32, 4>(p, stream);

@@ -12,13 +12,15 @@ const char* last_dma_config();   // "<BM,BN,BK,NS,KG>" of the calling thread's l
 // 16-byte aligned operands (every tile interior); returns an error otherwise.
 struct EpiFold {
     float* aux_out = nullptr; int64_t ld_aux = 0; const float* aux_mul = nullptr; int aux_add_one = 0;
+    uint16_t* aux_bf = nullptr; int64_t ld_aux_bf = 0;     // bf16 copy of the product (bf16-operand sampler)
     float* stat_out = nullptr;
     const float* ln_stats = nullptr; const float* ln_c1 = nullptr; int ln_nseg = 0; float ln_fold_eps = 0.f;
 };
 int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t stream);
 // c-tables of the folded LayerNorm for T steps: c1[(k*L+l)*FF + j] = sum_i (1 + scale_kl[i]) W1_l[j][i], c2 likewise from the shifts
 // (+ b1); c1f/c2f (D) for norm -> out_proj.  One launch (vita_elementwise.hip).
-int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s);
+int launch_ln_fold_tables_all(const vita_flownet_weights* w, const float* mod, int T, float* c1, float* c2, float* c1f, float* c2f, hipStream_t s,
+                              const vita_bf16_weights* bw = nullptr);   // bw: take the GEMM weights from the bf16 copies (row stride r8(H))
 // the persistent Euler sampler (vita_ode_persistent.hip): one launch for all K steps at chip-filling batches
 bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* x0, int64_t ldx0, const float* x_out, int64_t ldo);
 size_t ode_persistent_sync_bytes(int K, int L);
@@ -28,12 +30,17 @@ size_t ode_persistent_status_offset();
 int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
                           float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,
                           const float* c1f, const float* c2f, void* sync, hipStream_t s);
+int launch_ode_persistent_bf16(const vita_flownet_weights* w, const vita_bf16_weights* bw, const float* x0, int64_t ldx0, const uint16_t* x0b,
+                               float* x_out, int64_t ldo, uint16_t* xb_mid, uint16_t* xb_final, int B, int K, float dt, float* h, uint16_t* hnb,
+                               uint16_t* ub, float* stat, const float* mod, const float* c1, const float* c2, const float* c1f, const float* c2f,
+                               void* sync, hipStream_t s);
 int launch_sinusoid(const float* t, float* out, int64_t ldo, int B, int dim, hipStream_t s);
 int launch_step_times(float* ts, int K, hipStream_t s);
 int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int H, float eps, int mode, const float* mul,
                   int64_t ld_mul, const float* add, int64_t ld_add, hipStream_t s, uint16_t* ybf = nullptr, int64_t ld_ybf = 0);
 struct SplitK;
-int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk = nullptr);
+int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk = nullptr,
+                  const EpiFold* fold = nullptr);
 int launch_pack_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int cols, hipStream_t s);
 int launch_pack_bf16_t(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int K, int M, hipStream_t s);
 int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st);

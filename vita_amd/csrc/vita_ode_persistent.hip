@@ -53,6 +53,12 @@ struct OdeParams {
     int B, K;
     float dt;
     int TS;
+    // bf16-operand variant (vita_api_bf16.hip): GEMM operands bf16, everything else fp32.  bf16 != 0 selects it.
+    int bf16;
+    const uint16_t *in_wb, *out_wb, *fc1_wb[VITA_MAX_LAYERS], *fc2_wb[VITA_MAX_LAYERS];
+    const uint16_t* x0b;        // bf16 copy of x0 (step 0's A operand)
+    uint16_t *xb_mid, *xb_final; // bf16 state written by steps 0..K-2 / by the last step
+    uint16_t *hnb, *ub;          // bf16 h * mul and u
 };
 
 __device__ __forceinline__ unsigned long long clock64_shader() {   // shader clock (follows DVFS)
@@ -174,6 +180,27 @@ __global__ void ode_phase_table_kernel(OdeParams q, PhaseDesc* table) {
         else { g.epi.aux_mul = q.w.norm_w; g.epi.aux_add_one = 0; }
         d.ntiles = 4 * (H / 128);
     }
+    if (q.bf16) {
+        // same chain on bf16 operands: A / W pointers and strides count 4-byte units (bf16 pairs); the fp32 residual stream h,
+        // the Euler state x and the statistics stay; products a GEMM consumes are written as bf16 only
+        const uint16_t* xbs = k == 0 ? q.x0b : q.xb_mid;
+        uint16_t* xbd = k == q.K - 1 ? q.xb_final : q.xb_mid;
+        auto f = [](const uint16_t* p_) { return reinterpret_cast<const float*>(p_); };
+        g.epi.aux_out = nullptr;
+        if (is_in) {
+            g.X = f(xbs); g.ldx = D / 2; g.W = f(q.in_wb); g.ldw = D / 2; g.K = D / 2;
+            g.epi.aux_bf = q.hnb; g.epi.ld_aux_bf = H;
+        } else if (is_out) {
+            g.X = f(q.hnb); g.ldx = H / 2; g.W = f(q.out_wb); g.ldw = H / 2; g.K = H / 2;
+            g.epi.ybf = xbd; g.epi.ld_ybf = D;
+        } else if (is_fc1) {
+            g.X = f(q.hnb); g.ldx = H / 2; g.W = f(q.fc1_wb[l]); g.ldw = H / 2; g.K = H / 2;
+            g.epi.Y = nullptr; g.epi.ybf = q.ub; g.epi.ld_ybf = FF;
+        } else {
+            g.X = f(q.ub); g.ldx = FF / 2; g.W = f(q.fc2_wb[l]); g.ldw = FF / 2; g.K = FF / 2;
+            g.epi.aux_bf = q.hnb; g.epi.ld_aux_bf = H;
+        }
+    }
     table[phase] = d;
 }
 
@@ -185,6 +212,7 @@ struct PersistArgs {
     unsigned long long* stamps;   // diagnostic: NULL, or [workgroup][phase][6] clocks: 100 MHz (phase start, wait over, tiles done, published), shader (start, published)
 };
 
+template <bool BF16>
 __global__ __launch_bounds__(DNT, 2) void ode_persistent_kernel(PersistArgs q) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* flag = smem + kStageFloats + 2 * P_BM1;
@@ -219,10 +247,10 @@ __global__ __launch_bounds__(DNT, 2) void ode_persistent_kernel(PersistArgs q) {
             if (!first) __syncthreads();          // the previous tile's epilogue is done with the stage buffers
             bool ok;
             if (d.big) {                          // 256 x 128 tiles
-                ok = dma_tile<P_BM1, P_BN, P_BK1, P_NS, false, false, 1, false, true, VITA_ACT_GELU_TANH>(d.g, smem, rg, t, 0, sy);
+                ok = dma_tile<P_BM1, P_BN, P_BK1, P_NS, false, BF16, 1, false, true, VITA_ACT_GELU_TANH>(d.g, smem, rg, t, 0, sy);
             } else {                              // 64 x 128 tiles over the team's 256 x N block
                 const int tn = d.g.N / P_BN;
-                ok = dma_tile<P_BM2, P_BN, P_BK2, P_NS, false, false, 4, false, true, VITA_ACT_NONE>(d.g, smem, rg * 4 + t / tn, t % tn, 0, sy);
+                ok = dma_tile<P_BM2, P_BN, P_BK2, P_NS, false, BF16, 4, false, true, VITA_ACT_NONE>(d.g, smem, rg * 4 + t / tn, t % tn, 0, sy);
             }
             if (!ok) return;
             sy.target = 0;
@@ -277,36 +305,60 @@ bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* 
     return true;
 }
 
-// Enqueues the memset of the hand-off state and the persistent launch(es).  The time-path tables (mod, c1, c2, c1f, c2f)
-// must already be enqueued on `s`.
-int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B,
-                          int K, float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,
-                          const float* c1f, const float* c2f, void* sync, hipStream_t s) {
-    const int TS = w->FF / 128;
+// Enqueues the phase-table build, the memset of the hand-off state and the persistent launch(es).
+static int launch_persistent(OdeParams& q, int L, void* sync, hipStream_t s) {
+    const int TS = q.TS;
     const int rg_per_launch = 256 / TS;
     const size_t lds = kSmemFloats * sizeof(float);
-    const int nphases = K * (2 + 2 * w->L);
+    const int nphases = q.K * (2 + 2 * L);
     PhaseDesc* table = reinterpret_cast<PhaseDesc*>(static_cast<char*>(sync) + ((sync_words_bytes() + 255) & ~size_t(255)));
-    OdeParams q{};
-    q.w = *w;
-    q.x0 = x0; q.ldx0 = ldx0; q.x_out = x_out; q.ldo = ldo; q.traj = traj;
-    q.h = h; q.hn = hn; q.u = u; q.stat = stat;
-    q.mod = mod; q.c1 = c1; q.c2 = c2; q.c1f = c1f; q.c2f = c2f;
-    q.B = B; q.K = K; q.dt = dt; q.TS = TS;
     hipLaunchKernelGGL(ode_phase_table_kernel, dim3((unsigned)((nphases + 63) / 64)), dim3(64), 0, s, q, table);
     VITA_CHECK_HIP(hipGetLastError());
     PersistArgs a{};
     a.table = table; a.sync = static_cast<unsigned*>(sync); a.nphases = nphases; a.TS = TS;
     a.spin_limit = 1u << 22;      // ~ seconds: only a lost workgroup gets there
     a.stamps = g_stamps.load();
-    for (int rg0 = 0; rg0 < B / 256; rg0 += rg_per_launch) {
+    for (int rg0 = 0; rg0 < q.B / 256; rg0 += rg_per_launch) {
         a.rg0 = rg0;
         // counters + timeout word before every launch; the sticky status word only with the call's first launch
         VITA_CHECK_HIP(hipMemsetAsync(sync, 0, rg0 == 0 ? sync_words_bytes() : (size_t)kSyncWords * sizeof(unsigned), s));
-        hipLaunchKernelGGL(ode_persistent_kernel, dim3((unsigned)(rg_per_launch * TS)), dim3(DNT), lds, s, a);
+        if (q.bf16) hipLaunchKernelGGL(ode_persistent_kernel<true>, dim3((unsigned)(rg_per_launch * TS)), dim3(DNT), lds, s, a);
+        else hipLaunchKernelGGL(ode_persistent_kernel<false>, dim3((unsigned)(rg_per_launch * TS)), dim3(DNT), lds, s, a);
         VITA_CHECK_HIP(hipGetLastError());
     }
     return VITA_OK;
+}
+
+// The time-path tables (mod, c1, c2, c1f, c2f) must already be enqueued on `s`.
+int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B,
+                          int K, float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,
+                          const float* c1f, const float* c2f, void* sync, hipStream_t s) {
+    OdeParams q{};
+    q.w = *w;
+    q.x0 = x0; q.ldx0 = ldx0; q.x_out = x_out; q.ldo = ldo; q.traj = traj;
+    q.h = h; q.hn = hn; q.u = u; q.stat = stat;
+    q.mod = mod; q.c1 = c1; q.c2 = c2; q.c1f = c1f; q.c2f = c2f;
+    q.B = B; q.K = K; q.dt = dt; q.TS = w->FF / 128;
+    return launch_persistent(q, w->L, sync, s);
+}
+
+// bf16-operand variant: x0 / x_out are the fp32 Euler state (x_out may alias x0), x0b its bf16 copy, xb_final receives the
+// bf16 copy of the result (may alias x0b), xb_mid the steps in between; hnb / ub are the bf16 activations.
+int launch_ode_persistent_bf16(const vita_flownet_weights* w, const vita_bf16_weights* bw, const float* x0, int64_t ldx0, const uint16_t* x0b,
+                               float* x_out, int64_t ldo, uint16_t* xb_mid, uint16_t* xb_final, int B, int K, float dt, float* h, uint16_t* hnb,
+                               uint16_t* ub, float* stat, const float* mod, const float* c1, const float* c2, const float* c1f, const float* c2f,
+                               void* sync, hipStream_t s) {
+    OdeParams q{};
+    q.w = *w;
+    q.x0 = x0; q.ldx0 = ldx0; q.x_out = x_out; q.ldo = ldo; q.traj = nullptr;
+    q.h = h; q.hn = nullptr; q.u = nullptr; q.stat = stat;
+    q.mod = mod; q.c1 = c1; q.c2 = c2; q.c1f = c1f; q.c2f = c2f;
+    q.B = B; q.K = K; q.dt = dt; q.TS = w->FF / 128;
+    q.bf16 = 1;
+    q.in_wb = bw->in_w; q.out_wb = bw->out_w;
+    for (int l = 0; l < w->L; ++l) { q.fc1_wb[l] = bw->fc1_w[l]; q.fc2_wb[l] = bw->fc2_w[l]; }
+    q.x0b = x0b; q.xb_mid = xb_mid; q.xb_final = xb_final ? xb_final : xb_mid; q.hnb = hnb; q.ub = ub;
+    return launch_persistent(q, w->L, sync, s);
 }
 
 }  // namespace vita
