@@ -207,19 +207,25 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     chunks_per_s = world * B * args.steps / elapsed
 
-    # latent-only sampler (B,D)->(B,D): "the fused ODE sampler" of the north star
+    # latent-only sampler (B,D)->(B,D): "the fused ODE sampler" of the north star.  At chip-filling batches it is ONE persistent
+    # launch per solve (+ a few tiny time-path launches): HIP events on the launch stream around n solves
     x0 = torch.randn(B, fw.D, generator=g).to(dev)
     for _ in range(2):
         ops.ode_sample(fw, x0, K)
     torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
     n_lat = max(3, args.steps // 2)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record()
     for _ in range(n_lat):
         ops.ode_sample(fw, x0, K)
-    torch.cuda.synchronize(dev)
-    lat_ms = (time.perf_counter() - t0) * 1e3 / n_lat
+    ev1.record()
+    ev1.synchronize()
+    lat_ms = ev0.elapsed_time(ev1) / n_lat
     f_step = 2 * fw.D * fw.H + fw.L * 4 * fw.H * fw.FF + 2 * fw.H * fw.D
     lat_tflops = B * K * f_step / (lat_ms * 1e-3) / 1e12
+    import ctypes
+    persistent = bool(lib.vita_ode_sample_takes_persistent(ctypes.byref(fw.w), B))
+    sampler_status = ops.ode_sample_status(fw, B, K, dev)
 
     # ---- bf16-operand variant of the same path (side figure: NOT the headline, the reference is strict fp32)
     bf16 = None
@@ -402,8 +408,9 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("shape") == [B, fw.FF, fw.H]:
-                traffic, traffic_src = tj.get("fc1_hbm_bytes_per_launch"), f"{tj.get('source')} (PMC passes on shape {tj.get('shape')}, not this run)"
+            want = ["persistent", B, K, fw.H] if persistent else [B, fw.FF, fw.H]
+            if tj.get("shape") == want:
+                traffic, traffic_src = tj.get("hbm_bytes_per_launch"), f"{tj.get('source')} (PMC passes on {tj.get('kernel')}, shape {tj.get('shape')}, not this run)"
         except Exception:
             traffic = None
 
@@ -412,6 +419,22 @@ def main():
         cpu = cpu_baseline(args, sd, obs, K, A, fpc)
 
     if rank == 0:
+        if persistent:
+            # the dominant kernel IS the solve: one persistent launch runs all K steps (K * (2 + 2L) GEMM phases)
+            roofline = {"bound": "mfma",
+                        "kernel": f"ode_persistent_kernel<false> B={B} K={K}: {K * (2 + 2 * fw.L)} phases, fc1 tiles <256,128,32,3>, input/fc2/output "
+                                  f"projection tiles <64,128,64,3,KG=4>, teams of {fw.FF // 128} workgroups per 256 rows",
+                        "achieved": round(lat_tflops, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(lat_tflops / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                        "flops_per_launch": float(B) * K * f_step, "avg_launch_us": round(lat_ms * 1e3, 2), "sampler_status": sampler_status,
+                        "timing": "HIP events on the launch stream around back-to-back solves; one solve = the phase-table kernel, a memset, the "
+                                  "persistent launch and the time path's ~8 tiny launches (all inside the interval); flops = the algorithmic "
+                                  "x-dependent GEMM flops of SURVEY 8(d): B * K * F_step"}
+        else:
+            roofline = {"bound": "mfma", "kernel": dom, "achieved": kernels[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic, "traffic_source": traffic_src,
+                        "flops_per_launch": 2.0 * B * fw.FF * fw.H, "avg_launch_us": kernels[dom]["avg_us"],
+                        "timing": "HIP events around 20 back-to-back launches on the launch stream"}
         line = {
             "metric": "ODE action-chunks/sec (bs 4096)",
             "value": round(chunks_per_s, 1),
@@ -430,13 +453,7 @@ def main():
             "latent_only": {"ms_per_solve": round(lat_ms, 4), "chunks_per_s": round(B / (lat_ms * 1e-3), 1),
                             "tflops": round(lat_tflops, 2),
                             "frac_of_f32_mfma_peak": round(lat_tflops / PEAK_F32_MFMA_TFLOPS, 4)},
-            "roofline": {"bound": "mfma", "kernel": dom,
-                         "achieved": kernels[dom]["tflops"], "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": kernels[dom]["frac_of_f32_mfma_peak"], "traffic": traffic, "traffic_source": traffic_src,
-                         "flops_per_launch": 2.0 * B * fw.FF * fw.H,
-                         "avg_launch_us": kernels[dom]["avg_us"],
-                         "timing": "HIP events around 20 back-to-back launches on the launch stream: includes the gap between "
-                                   "dependent kernels; rocprofv3's per-kernel duration (profiles/) excludes it, see DESIGN.md section 4"},
+            "roofline": roofline,
             "kernels": kernels,
             "hbm_bound_kernels": {"peak_GB_per_s": 8000, "note": "wrapper calls incl. their output allocation; algorithmic bytes = reads + writes "
                                   "of the operands once", "kernels": hbm},

@@ -165,6 +165,8 @@ int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num
 /* process-wide switch between the persistent launch (1, default unless VITA_NO_PERSISTENT=1) and the per-launch path (0);
  * returns the previous setting.  Both produce the same bits. */
 int vita_ode_sample_set_persistent(int32_t on);
+/* 1 when vita_ode_sample_f32 on a contiguous, 16-byte aligned (B, D) state takes the persistent launch under the current switch */
+int vita_ode_sample_takes_persistent(const vita_flownet_weights* w, int32_t B);
 /* diagnostic: NULL (default), or a device buffer of 256 * num_steps * (2 + 2L) * 6 uint64 that the persistent launches of this
  * process fill with 100 MHz clock stamps per workgroup and phase: phase start, wait over, tiles done, published, then the shader clock at start and publish (tools/persistent_stamps.py) */
 int vita_debug_ode_stamps(void* device_buf);

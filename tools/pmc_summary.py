@@ -19,7 +19,7 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_*"))):
     kern = None
     for f in glob.glob(os.path.join(d, "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if "gemm" in r["Kernel_Name"]:
+            if ("ode_persistent_kernel" in r["Kernel_Name"]) if name == "persistent" else ("gemm" in r["Kernel_Name"]):
                 kern = r["Kernel_Name"]
                 ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
     if not ctr:
@@ -39,7 +39,13 @@ for d in sorted(glob.glob(os.path.join(root, "gpurun_out", f"pmc_{tag}_*"))):
     out[name] = s
 os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
 json.dump(out, open(os.path.join(root, "profiles", f"{tag}_pmc.json"), "w"), indent=1)
-if "fc1" in out and "hbm_bytes_per_launch" in out["fc1"]:
-    json.dump({"fc1_hbm_bytes_per_launch": out["fc1"]["hbm_bytes_per_launch"], "source": f"profiles/{tag}_pmc.json"},
+# what bench.py quotes as roofline.traffic: the dominant kernel's HBM bytes per launch, with the shape it was measured on
+if "persistent" in out and "hbm_bytes_per_launch" in out["persistent"]:
+    json.dump({"hbm_bytes_per_launch": out["persistent"]["hbm_bytes_per_launch"], "shape": ["persistent", 4096, 6, 512],
+               "kernel": "ode_persistent_kernel<false>", "source": f"profiles/{tag}_pmc.json"},
+              open(os.path.join(root, "profiles", "traffic.json"), "w"))
+elif "fc1" in out and "hbm_bytes_per_launch" in out["fc1"]:
+    json.dump({"hbm_bytes_per_launch": out["fc1"]["hbm_bytes_per_launch"], "shape": [4096, 2048, 512],
+               "kernel": out["fc1"]["kernel"], "source": f"profiles/{tag}_pmc.json"},
               open(os.path.join(root, "profiles", "traffic.json"), "w"))
 print(json.dumps(out, indent=1))

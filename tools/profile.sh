@@ -26,4 +26,15 @@ for k in "fc1 4096 2048 512 0 3 0" "fc2 4096 512 2048 0 0 1"; do
   pass $d sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE -- "$@" || exit 1
   pass $d tcc TCC_HIT_sum TCC_MISS_sum -- "$@" || exit 1
 done
+# the persistent sampler (one launch per solve): the same counter passes over tools/persistent_only.py
+d=gpurun_out/pmc_${tag}_persistent
+mkdir -p $d
+ppass() {  # ppass <name> <counters...>
+  local n=$1; shift
+  timeout -s KILL 120 rocprofv3 --pmc "$@" --output-format csv -d $d -o $n -- python3 tools/persistent_only.py 6 > $d/$n.log 2>&1 || { tail -5 $d/$n.log; return 1; }
+}
+ppass fetch FETCH_SIZE || exit 1
+ppass write WRITE_SIZE || exit 1
+ppass sq SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE || exit 1
+ppass tcc TCC_HIT_sum TCC_MISS_sum || exit 1
 echo profile done

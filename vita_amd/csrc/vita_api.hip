@@ -356,6 +356,10 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
 }
 
 int vita_ode_sample_set_persistent(int32_t on) { return set_ode_persistent(on); }
+int vita_ode_sample_takes_persistent(const vita_flownet_weights* w, int32_t B) {
+    if (!w || B <= 0 || !use_ln_fold(w, B)) return 0;
+    return ode_persistent_eligible(w, B, reinterpret_cast<const float*>(uintptr_t(256)), w->D, reinterpret_cast<const float*>(uintptr_t(256)), w->D) ? 1 : 0;
+}
 int vita_debug_ode_stamps(void* device_buf) { set_ode_persistent_stamps(device_buf); return VITA_OK; }
 
 int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status) {
