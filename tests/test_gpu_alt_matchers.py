@@ -96,6 +96,39 @@ def test_consistency_sampler_default_dims_vs_oracle_fp64(ops, dev, B, K, sigma_v
     assert torch.isfinite(got).all() and nerr(got[:n], ref) <= TOL
 
 
+def test_alt_matchers_return_traces(ops, dev, alt):
+    """return_traces of the two alternate samplers (mean_flow_matcher.py:217-233, consistency_flow_matcher.py:84-106): list
+    lengths and contents as the reference builds them (MeanFlow: K+1 entries starting at x0 with a zero velocity; Consistency:
+    K entries), the last history entry equal to the fused sampler's result within TOL, and x itself the fused result's bits."""
+    from vita_amd import flow
+    sd = {k[len("mf/sd/"):]: v for k, v in alt.items() if k.startswith("mf/sd/")}
+    mw = ops.MeanFlowNetHandle(sd, dev)
+    m = flow.get_flow_matcher("mean", num_sampling_steps=1)
+    x0 = alt["mf/x"].to(dev)
+    for K in (1, 2, 5):
+        x, (traj, vel) = m.sample(mw, tuple(x0.shape), dev, num_steps=K, return_traces=True, start=x0)
+        assert torch.equal(x, m.sample(mw, tuple(x0.shape), dev, num_steps=K, start=x0))
+        assert nerr(x, alt[f"mf/sample/K{K}"]) <= TOL
+        assert len(traj) == len(vel) == K + 1 and all(not h.is_cuda for h in traj + vel)
+        assert torch.equal(traj[0], x0.cpu()) and not vel[0].any()
+        assert nerr(traj[-1], alt[f"mf/sample/K{K}"]) <= TOL
+        for k in range(K):                                  # x_{k+1} = x_k - u_k / K
+            assert nerr(traj[k + 1], traj[k] - vel[k + 1] / K) <= 1e-6
+    sd = {k[len("cfm/sd/"):]: v for k, v in alt.items() if k.startswith("cfm/sd/")}
+    fw = ops.FlowNetHandle(sd, dev)
+    x0 = alt["cfm/x0"].to(dev)
+    for K in (1, 4):
+        for sigma_var, key in ((0.0, "det"), (1.0, "sde")):
+            c = flow.get_flow_matcher("consistency", num_sampling_steps=1, sigma_var=sigma_var)
+            noise = alt[f"cfm/sde/noise{K}"].to(dev) if sigma_var > 0 else None
+            z, (traj, vel) = c.sample(fw, tuple(x0.shape), dev, num_steps=K, return_traces=True, start=x0, noise=noise)
+            assert torch.equal(z, c.sample(fw, tuple(x0.shape), dev, num_steps=K, start=x0, noise=noise))
+            assert len(traj) == len(vel) == K and all(not h.is_cuda for h in traj + vel)
+            assert nerr(traj[-1], alt[f"cfm/{key}/K{K}"]) <= TOL and nerr(z, alt[f"cfm/{key}/K{K}"]) <= TOL
+            v0 = ops.flownet_forward(fw, x0, torch.full((x0.shape[0],), c.eps, device=dev))
+            assert torch.equal(vel[0], v0.cpu())
+
+
 def test_alt_sampler_errors(ops, dev):
     from vita_amd._lib import VitaHipError
     sd = O.make_state_dict(20, 7, latent_dim=32, hidden_dim=32, num_layers=2, ae_hidden=32, ae_layers=2, time_embed_dim=64, seed=4)

@@ -186,9 +186,25 @@ class MeanFlowMatcher(_InferenceOnlyMatcher):
             raise ValueError("MeanFlowMatcher requires a 'start' (vision latent) tensor for sampling.")      # :205-206
         if not isinstance(model, ops.MeanFlowNetHandle):
             raise TypeError("MeanFlowMatcher.sample needs a SimpleMeanFlowNet (policy.flow_net.name: simple_mean_flow_net)")
-        if return_traces:
-            raise NotImplementedError("return_traces is not built for the MeanFlow sampler")
-        return ops.meanflow_sample(model, start, self.num_sampling_steps if num_steps is None else num_steps)
+        num_steps = self.num_sampling_steps if num_steps is None else num_steps
+        x = ops.meanflow_sample(model, start, num_steps)
+        if not return_traces:
+            return x
+        # :217-230 — the per-step CPU copies of x and of the mean velocity.  The returned x is the fused sampler's (the
+        # same bits as without traces); the histories re-run the steps one vita_meanflow_forward_f32 call at a time.
+        xk = start.detach().float()
+        traj_history, vel_history = [xk.clone().cpu()], [torch.zeros_like(xk).cpu()]
+        B = xk.shape[0]
+        for step in range(num_steps):
+            t_scalar = 1.0 - step / num_steps
+            h_scalar = t_scalar - (1.0 - (step + 1) / num_steps)
+            t = torch.full((B,), t_scalar, device=xk.device)
+            h = torch.full((B,), h_scalar, device=xk.device)
+            u, _ = ops.meanflow_forward(model, xk, t, h, need_v=False)
+            xk = xk - h.view(-1, 1) * u
+            traj_history.append(xk.clone().cpu())
+            vel_history.append(u.clone().cpu())
+        return x, (traj_history, vel_history)
 
 
 class MeanFlowConditionalFlowMatcher(MeanFlowMatcher):
@@ -230,13 +246,31 @@ class ConsistencyFlowMatcher(_InferenceOnlyMatcher):
     def sample(self, model: "ops.FlowNetHandle", shape, device, num_steps=None, return_traces=False, start=None, noise=None, **kwargs):
         if num_steps is None:
             num_steps = self.num_sampling_steps
-        if return_traces:
-            raise NotImplementedError("return_traces is not built for the Consistency-FM sampler")
         z = torch.randn(shape, device=device) if start is None else start
         if self.sigma_var > 0 and noise is None:
             noise = torch.randn((num_steps,) + tuple(z.shape), device=z.device, dtype=torch.float32)
-        return ops.consistency_sample(model, z, num_steps, eps=self.eps, sigma_var=self.sigma_var, noise_scale=self.noise_scale,
-                                      noise=noise)
+        out = ops.consistency_sample(model, z, num_steps, eps=self.eps, sigma_var=self.sigma_var, noise_scale=self.noise_scale,
+                                     noise=noise)
+        if not return_traces:
+            return out
+        # :84-104 — per-step CPU copies of z and vt (no initial entry, unlike the Euler and MeanFlow samplers).  The returned
+        # z is the fused sampler's; the histories re-run the steps one vita_flownet_forward_f32 call at a time on the same noise.
+        zk = z.detach().float()
+        traj_history, vel_history = [], []
+        dt = 1.0 / num_steps
+        for i in range(num_steps):
+            num_t = i / num_steps * (1 - self.eps) + self.eps
+            vt = ops.flownet_forward(model, zk, torch.full((zk.shape[0],), num_t, device=zk.device))
+            sigma_t = self.sigma_t(num_t)
+            if sigma_t > 0:
+                pred_sigma = vt + (sigma_t ** 2) / (2 * (self.noise_scale ** 2) * ((1 - num_t) ** 2)) * \
+                    (0.5 * num_t * (1 - num_t) * vt - 0.5 * (2 - num_t) * zk)
+                zk = zk + pred_sigma * dt + sigma_t * float(np.sqrt(dt)) * noise[i].to(zk.device)
+            else:
+                zk = zk + vt * dt
+            traj_history.append(zk.clone().cpu())
+            vel_history.append(vt.clone().cpu())
+        return out, (traj_history, vel_history)
 
 
 FLOW_MATCHER_CLASSES = {                       # flow_matchers.py:137-145
