@@ -145,6 +145,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=40.0, help="time box of the whole cpu_baseline leg")
     ap.add_argument("--dry-launch", action="store_true", help="ranks print their launch environment as JSON and exit (no GPU touched): "
                                                               "the CPU-side test of the N>1 self-launch")
+    ap.add_argument("--rehearse-dist", action="store_true", help="N=1 only: initialise the RCCL process group with one rank and issue "
+                                                                 "every collective of the N>1 path anyway (a rehearsal of that path on a one-GPU box)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -163,10 +165,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    multi = world > 1 or args.rehearse_dist
+    if multi:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if "MASTER_PORT" not in os.environ:        # --rehearse-dist started by hand
+            import socket
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     from vita_amd import ops, _lib
     from vita_amd.synthetic import make_state_dict
@@ -261,7 +269,7 @@ def main():
         torch.manual_seed(0)
         pol = VitaPolicy(cfg, stats)
         pol.load_state_dict({k: v for k, v in sd.items()}, strict=False)
-        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100000, group=group)
+        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100000, group=group, rehearse_collectives=args.rehearse_dist and all_ranks)
         gt = torch.Generator().manual_seed(100 + rank)
         ncam = len(cfg.task.image_keys)
         tbatch = {cfg.task.state_key: torch.randn(TB, 1, S, generator=gt).to(dev),
@@ -290,7 +298,7 @@ def main():
                "ms_per_step": round(tel * 1e3 / nts, 4), "steps": nts, "batch_per_gpu": TB, "global_batch": TB * w_,
                "dtype": "f32" if gemm_dtype == "f32" else "bf16 GEMM operands (calls >= 2^31 FLOP), f32 accumulate / master weights / gradients",
                "loss": round(m["loss"], 6), "grad_norm": round(m["grad_norm"], 6),
-               "grad_bytes_allreduced_per_step": int(tr.flat_grad.numel() * 4) if w_ > 1 else 0,
+               "grad_bytes_allreduced_per_step": int(tr.flat_grad.numel() * 4) if tr.reducer.active else 0,
                "parallelism": f"data-parallel x{w_}, 3 event-driven gradient buckets over RCCL" if w_ > 1 else "single GPU",
                "includes": "normalize, fused forward+backward (1 FM eval + K Euler steps + encoder + 2 decodes), grad-norm clip, AdamW, EMA; observer excluded (camera latents are the input)",
                "algorithmic_flops_per_sample_fwd_bwd": f_train}
@@ -305,7 +313,7 @@ def main():
         print("bench.py: the training leg uses the default policy dims; skipped for --hidden != 512", file=sys.stderr)
     if not args.no_train and args.hidden == 512:
         train = train_leg(args.train_batch, "f32", args.train_steps or args.steps, True)
-        if world > 1:
+        if multi:
             # the same step without the collective (each rank alone in a one-rank group): what the all-reduce leaves exposed
             try:
                 solo_groups = [dist.new_group([r]) for r in range(world)]

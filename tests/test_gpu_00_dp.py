@@ -113,3 +113,52 @@ def test_two_rank_data_parallel_equals_single_process_on_the_global_batch():
     err = ((p0 - ref).abs().max() / ref.abs().max()).item()
     assert err <= 2e-5, f"data-parallel parameters differ from the single-process run: {err:g}"
     assert abs(gn0 - tr.metrics()["grad_norm"]) <= 1e-4 * gn0
+
+
+def _rccl_worker(rank, port, out):
+    import faulthandler
+    dbg = os.environ.get("VITA_DP_DEBUG_DIR")
+    if dbg:
+        faulthandler.dump_traceback_later(60, repeat=False, file=open(os.path.join(dbg, "dp_rccl_rank0.txt"), "w"), exit=True)
+    import torch.distributed as dist
+    from vita_amd.trainer import PolicyTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)       # as bench.py does for N > 1
+    try:
+        cfg = _cfg()
+        tr = PolicyTrainer(cfg, _policy(cfg), dev, num_training_steps=100, max_bucket_elems=20000, rehearse_collectives=True)
+        assert tr.reducer.active and not tr.reducer.host_staged and tr.events is not None and tr.reducer.stream is not None
+        for batch, t in _batches(cfg, B, STEPS):
+            tr.train_step(batch, t=t.to(dev))
+        dist.barrier()
+        torch.cuda.synchronize()
+        out["rccl"] = (tr.flat.cpu(), tr.ema.cpu(), tr.metrics()["grad_norm"])
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_branch_one_rank_rehearsal_equals_the_plain_trainer():
+    """The RCCL ("nccl") branch of BucketReducer / PolicyTrainer — in-place device all-reduce on the side stream behind the
+    per-layer gradient-ready events, parameter broadcast, barrier — executed for real in a one-rank group (the box has one
+    GPU and RCCL refuses two ranks on one device).  A sum over one rank is the identity, so three steps must leave exactly the
+    parameters, EMA and gradient norm of the trainer without a process group."""
+    from vita_amd.trainer import PolicyTrainer
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.start_processes(_rccl_worker, args=(_free_port(), out), nprocs=1, join=True, start_method="spawn")
+    p0, e0, gn0 = out["rccl"]
+    mgr.shutdown()
+    cfg = _cfg()
+    tr = PolicyTrainer(cfg, _policy(cfg), "cuda:0", num_training_steps=100)
+    assert not tr.reducer.active
+    for batch, t in _batches(cfg, B, STEPS):
+        tr.train_step(batch, t=t.to("cuda:0"))
+    torch.cuda.synchronize()
+    assert torch.equal(p0, tr.flat.cpu()) and torch.equal(e0, tr.ema.cpu())
+    assert gn0 == tr.metrics()["grad_norm"]

@@ -37,11 +37,15 @@ def world_info(group=None) -> Tuple[int, int]:
 class BucketReducer:
     """Sum-all-reduce contiguous segments of one flat buffer, each as soon as it is ready."""
 
-    def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None, max_bucket_elems: Optional[int] = None):
+    def __init__(self, flat: torch.Tensor, ranges: Sequence[Tuple[int, int]], group=None, max_bucket_elems: Optional[int] = None,
+                 rehearse: bool = False):
         if flat.dim() != 1 or not flat.is_contiguous():
             raise ValueError("BucketReducer needs a flat contiguous buffer")
         self.flat, self.group = flat, group
         self.rank, self.world = world_info(group)
+        # rehearse: issue the collectives even in a one-rank group (a sum over one rank is the identity) so the RCCL calls,
+        # the side stream and the event waits can be exercised on a one-GPU box
+        self.active = self.world > 1 or (rehearse and dist.is_available() and dist.is_initialized())
         # split oversized segments so a single RCCL call stays below max_bucket_elems (xGMI ring collectives are
         # per-link bound; a few tens of MB per call keeps the pipeline full without serialising on one giant op)
         self.segments: List[List[Tuple[int, int]]] = []
@@ -53,12 +57,12 @@ class BucketReducer:
                 parts.append((s, min(hi, s + step)))
             self.segments.append(parts)
         self.cuda = flat.is_cuda
-        self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.world > 1) else None
+        self.stream = torch.cuda.Stream(device=flat.device) if (self.cuda and self.active) else None
         self._handles = []
         # gloo has no device-side collectives: a GPU buffer is staged through pinned host memory by THIS class (explicit
         # copies on the side stream + gloo's CPU all-reduce) rather than by ProcessGroupGloo's own CUDA path, which hung
         # intermittently with two ranks on one device.  RCCL ("nccl") reduces in place on the device.
-        self.host_staged = bool(self.cuda and self.world > 1 and dist.get_backend(group) == "gloo")
+        self.host_staged = bool(self.cuda and self.active and dist.get_backend(group) == "gloo")
         self._pinned = None
         if self.host_staged:
             n = max((hi - lo for parts in self.segments for (lo, hi) in parts), default=0)
@@ -66,7 +70,7 @@ class BucketReducer:
 
     def reduce(self, i: int, ready_event: Optional["torch.cuda.Event"] = None) -> None:
         """Start the all-reduce of segment i (after `ready_event` on the side stream when given)."""
-        if self.world == 1:
+        if not self.active:
             return
         if self.cuda:
             if ready_event is not None:
@@ -94,7 +98,7 @@ class BucketReducer:
     def finish(self) -> float:
         """Make the compute stream wait for every started reduction; returns the factor (1/world) that turns the sums
         into means."""
-        if self.world > 1:
+        if self.active:
             if self.cuda:
                 torch.cuda.current_stream(self.flat.device).wait_stream(self.stream)
             else:

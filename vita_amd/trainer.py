@@ -31,7 +31,7 @@ from .policy import VitaPolicy, ema_decay, lr_lambda
 
 class PolicyTrainer:
     def __init__(self, config, policy: VitaPolicy, device, num_training_steps: Optional[int] = None, group=None,
-                 overlap: bool = True, max_bucket_elems: Optional[int] = 8 << 20):
+                 overlap: bool = True, max_bucket_elems: Optional[int] = 8 << 20, rehearse_collectives: bool = False):
         self.config, self.device = config, torch.device(device)
         self.network = policy.to(self.device)
         self.flat, self.flat_grad = policy.flatten_parameters()
@@ -41,10 +41,11 @@ class PolicyTrainer:
         self.rank, self.world = world_info(group)
         self.update_ranges = policy.trainable_ranges()    # frozen modules are skipped by the optimizer, as torch skips grad=None
         self.plan = policy.reduce_plan()              # [(lo, hi, event index)] in the order the backward makes them final
-        self.reducer = BucketReducer(self.flat_grad, [(lo, hi) for lo, hi, _ in self.plan], group, max_bucket_elems)
+        self.reducer = BucketReducer(self.flat_grad, [(lo, hi) for lo, hi, _ in self.plan], group, max_bucket_elems,
+                                     rehearse=rehearse_collectives)
         self.overlap = overlap
         self.events = None
-        if self.world > 1:
+        if self.reducer.active:
             self.events = [torch.cuda.Event() for _ in range(1 + max(ev for _, _, ev in self.plan))]
             for e in self.events:   # torch creates the hipEvent_t lazily, on the first record: the C side needs the handle
                 e.record(torch.cuda.current_stream(self.device))
@@ -53,7 +54,7 @@ class PolicyTrainer:
         self.losses = torch.zeros(max(L.LOSS_COUNT, L.MF_LOSS_COUNT), dtype=torch.float32, device=self.device)
         self.gnorm_sq = torch.zeros((), dtype=torch.float32, device=self.device)
         self.update_s = 0.0
-        if self.world > 1:
+        if self.reducer.active:
             self.broadcast_parameters(group)
 
     def broadcast_parameters(self, group=None):
