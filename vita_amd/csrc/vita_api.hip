@@ -25,6 +25,9 @@ void set_error(const char* fmt, ...) {
 // Size of the split-K region at the head of every carve below: kSplitkBytes for the workspace-taking entry points, smaller
 // inside the allocation-free entry point (vita_generate_actions_noalloc_f32), whose whole scratch is a fixed array.
 static thread_local size_t tl_skb = kSplitkBytes;
+// set while the allocation-free entry point runs: the workspace is a __device__ array of the code object, not hipMalloc memory
+// (the in-launch hand-off then keeps its agent-scope acquire, vita_ode_resident.hip)
+static thread_local bool tl_ws_symbol = false;
 struct SkbScope {
     size_t saved;
     explicit SkbScope(size_t n) : saved(tl_skb) { tl_skb = n; }
@@ -35,6 +38,8 @@ struct FlowWs {
     float *sk, *ts, *sin, *hid, *silu, *mod, *h, *hn, *u, *x;
     float *stat, *c1, *c2, *c1f, *c2f;   // folded LayerNorm (sampling at large batch): row statistics and the c-tables
     float* sync;                         // hand-off state of the persistent sampler (team counters, timeout / status words)
+    float* xi;                           // weights-resident sampler: the Euler state in the blocked hand-off layout
+    float *da, *db;                      // ... and the decoder's activations when it rides behind the last step
     size_t bytes;
 };
 
@@ -47,8 +52,9 @@ static bool use_ln_fold(const vita_flownet_weights* w, int B) {
     static const bool off = getenv("VITA_NO_LN_FOLD") != nullptr && atoi(getenv("VITA_NO_LN_FOLD")) != 0;
     return !off && B >= 1024 && B % 256 == 0 && w->L >= 1 && w->H % 128 == 0 && w->H <= 2048 && w->FF % 128 == 0 && w->D % 128 == 0;
 }
-// T = number of distinct timesteps (num_steps when sampling, B for per-row t)
-static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, bool need_x) {
+// T = number of distinct timesteps (num_steps when sampling, B for per-row t); sampling: one modulation row per step serves the
+// whole batch (the Euler sampler), so the in-launch samplers' tables and hand-off state may be needed
+static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, bool need_x, bool sampling) {
     Carver c(ws);
     FlowWs f;
     f.sk = c.take(tl_skb / sizeof(float));
@@ -57,12 +63,19 @@ static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, 
     f.hid = c.take((size_t)T * 4 * w->TE);
     f.silu = c.take((size_t)T * w->H);
     f.mod = c.take((size_t)T * w->L * 3 * w->H);
-    f.h = c.take((size_t)B * w->H);
+    const size_t Bp = ((size_t)B + 3) & ~size_t(3);   // the blocked hand-off layout of the resident sampler pads rows to 4
+    f.h = c.take(Bp * w->H);
     f.hn = c.take((size_t)B * w->H);
-    f.u = c.take((size_t)B * w->FF);
+    f.u = c.take(Bp * w->FF);
     f.x = need_x ? c.take((size_t)B * w->D) : nullptr;
-    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = f.sync = nullptr;
-    if (T != B && use_ln_fold(w, B)) {   // sampling only (per-row t has per-row modulation: no shared tables)
+    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = f.sync = f.xi = f.da = f.db = nullptr;
+    if (sampling && ode_resident_dims(w, B)) {
+        f.sync = c.take(ode_persistent_sync_bytes(0, 0) / sizeof(float));   // hand-off words only
+        f.xi = c.take(Bp * w->D);
+        f.da = c.take(Bp * w->D);        // decoder hidden width == D on that path (ode_resident_decoder_ok)
+        f.db = c.take(Bp * w->D);
+    }
+    if (sampling && use_ln_fold(w, B)) {   // sampling only (per-row t has per-row modulation: no shared tables)
         f.sync = c.take(ode_persistent_sync_bytes(T, w->L) / sizeof(float));
         f.stat = c.take((size_t)(w->H / 128) * B * 2);
         f.c1 = c.take((size_t)T * w->L * w->FF);
@@ -173,10 +186,13 @@ static int flow_eval_folded(const vita_flownet_weights* w, const FlowWs& f, cons
     return gemm_f32_fold(o, c, s);
 }
 
+// dec / actions / lda: the action decoder to run behind the last step when the weights-resident launch takes the solve;
+// *dec_done says whether it did (otherwise the caller runs decoder_forward).
 static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
-                      float* traj, void* ws, hipStream_t s) {
+                      float* traj, void* ws, hipStream_t s, const vita_decoder_weights* dec = nullptr, float* actions = nullptr,
+                      int64_t lda = 0, bool* dec_done = nullptr) {
     const int D = w->D, H = w->H, L = w->L;
-    FlowWs f = carve_flow(ws, w, B, K, false);
+    FlowWs f = carve_flow(ws, w, B, K, false, true);
     SplitkScope sk(f.sk, tl_skb);
     VITA_TRY(launch_step_times(f.ts, K, s));
     VITA_TRY(time_path(w, f, K, s));
@@ -189,6 +205,17 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
         // all K steps in one persistent launch (vita_ode_persistent.hip): same tiles, same epilogues, same bits
         VITA_TRY(launch_ode_persistent(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.hn, f.u, f.stat, f.mod, f.c1, f.c2, f.c1f, f.c2f,
                                        f.sync, s));
+        if (traj)
+            VITA_CHECK_HIP(hipMemcpy2DAsync(x_out, (size_t)ldo * 4, traj + (size_t)K * B * D, (size_t)D * 4, (size_t)D * 4, (size_t)B,
+                                            hipMemcpyDeviceToDevice, s));
+        return VITA_OK;
+    }
+    if (f.sync && ode_resident_eligible(w, B, x0, ldx0, x_out, ldo)) {
+        // serving batches: one launch, the net's weights resident in LDS for all K steps (vita_ode_resident.hip)
+        const bool fuse_dec = dec != nullptr && dec->D == w->D && ode_resident_decoder_ok(dec, actions, lda);
+        VITA_TRY(launch_ode_resident(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.u, f.xi, f.mod, f.sync, tl_ws_symbol, s,
+                                     fuse_dec ? dec : nullptr, f.da, f.db, actions, lda));
+        if (dec_done) *dec_done = fuse_dec;
         if (traj)
             VITA_CHECK_HIP(hipMemcpy2DAsync(x_out, (size_t)ldo * 4, traj + (size_t)K * B * D, (size_t)D * 4, (size_t)D * 4, (size_t)B,
                                             hipMemcpyDeviceToDevice, s));
@@ -218,7 +245,7 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
 static int consistency_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
                               float eps, float sigma_var, float noise_scale, const float* noise, void* ws, hipStream_t s) {
     const int D = w->D, H = w->H, L = w->L;
-    FlowWs f = carve_flow(ws, w, B, K, true);
+    FlowWs f = carve_flow(ws, w, B, K, true, false);
     SplitkScope sk(f.sk, kSplitkBytes);
     VITA_TRY(launch_step_times_affine(f.ts, K, 1.0 - (double)eps, (double)eps, s));
     VITA_TRY(time_path(w, f, K, s));
@@ -321,7 +348,7 @@ int vita_linear_f32(const vita_linear_args* args, vita_stream_t stream) {
 
 size_t vita_flownet_forward_workspace_bytes(const vita_flownet_weights* w, int32_t B) {
     if (!w || B <= 0) return 0;
-    return carve_flow(nullptr, w, B, B, false).bytes;
+    return carve_flow(nullptr, w, B, B, false, false).bytes;
 }
 
 int vita_flownet_forward_f32(const vita_flownet_weights* w, const float* x, int64_t ldx, const float* t, float* v, int64_t ldv,
@@ -332,7 +359,7 @@ int vita_flownet_forward_f32(const vita_flownet_weights* w, const float* x, int6
     VITA_REQUIRE(x && t && v && ldx >= w->D && ldv >= w->D, "vita_flownet_forward_f32: bad x/t/v");
     VITA_TRY(check_ws(workspace, workspace_bytes, vita_flownet_forward_workspace_bytes(w, B), "vita_flownet_forward_f32"));
     hipStream_t s = (hipStream_t)stream;
-    FlowWs f = carve_flow(workspace, w, B, B, false);
+    FlowWs f = carve_flow(workspace, w, B, B, false, false);
     SplitkScope sk(f.sk, kSplitkBytes);
     VITA_CHECK_HIP(hipMemcpyAsync(f.ts, t, (size_t)B * 4, hipMemcpyDeviceToDevice, s));
     VITA_TRY(time_path(w, f, B, s));
@@ -341,7 +368,7 @@ int vita_flownet_forward_f32(const vita_flownet_weights* w, const float* x, int6
 
 size_t vita_ode_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {
     if (!w || B <= 0 || num_steps <= 0) return 0;
-    return carve_flow(nullptr, w, B, num_steps, false).bytes;
+    return carve_flow(nullptr, w, B, num_steps, false, true).bytes;
 }
 
 int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
@@ -357,7 +384,10 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
 
 int vita_ode_sample_set_persistent(int32_t on) { return set_ode_persistent(on); }
 int vita_ode_sample_takes_persistent(const vita_flownet_weights* w, int32_t B) {
-    if (!w || B <= 0 || !use_ln_fold(w, B)) return 0;
+    if (!w || B <= 0) return 0;
+    if (ode_resident_eligible(w, B, reinterpret_cast<const float*>(uintptr_t(256)), w->D, reinterpret_cast<const float*>(uintptr_t(256)), w->D))
+        return 2;     // the weights-resident launch of serving batches
+    if (!use_ln_fold(w, B)) return 0;
     return ode_persistent_eligible(w, B, reinterpret_cast<const float*>(uintptr_t(256)), w->D, reinterpret_cast<const float*>(uintptr_t(256)), w->D) ? 1 : 0;
 }
 int vita_debug_ode_stamps(void* device_buf) { set_ode_persistent_stamps(device_buf); return VITA_OK; }
@@ -365,7 +395,7 @@ int vita_debug_ode_stamps(void* device_buf) { set_ode_persistent_stamps(device_b
 int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status) {
     VITA_REQUIRE(w && workspace && status && B > 0 && num_steps > 0, "vita_ode_sample_status: bad arguments");
     *status = 0;
-    FlowWs f = carve_flow(const_cast<void*>(workspace), w, B, num_steps, false);
+    FlowWs f = carve_flow(const_cast<void*>(workspace), w, B, num_steps, false, true);
     if (f.sync == nullptr) return VITA_OK;      // shapes that never take the persistent launch
     unsigned v = 0;
     VITA_CHECK_HIP(hipMemcpy(&v, reinterpret_cast<const char*>(f.sync) + ode_persistent_status_offset(), sizeof(v), hipMemcpyDeviceToHost));
@@ -375,7 +405,7 @@ int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num
 
 size_t vita_consistency_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {
     if (!w || B <= 0 || num_steps <= 0) return 0;
-    return carve_flow(nullptr, w, B, num_steps, true).bytes;
+    return carve_flow(nullptr, w, B, num_steps, true, false).bytes;
 }
 
 int vita_consistency_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int32_t B,
@@ -412,7 +442,7 @@ size_t vita_generate_actions_workspace_bytes(const vita_flownet_weights* fw, con
                                              int32_t num_steps) {
     if (!fw || !dw || B <= 0 || num_steps <= 0) return 0;
     const size_t lat = ((size_t)B * fw->D * 4 + 255) & ~size_t(255);
-    const size_t a = carve_flow(nullptr, fw, B, num_steps, false).bytes;
+    const size_t a = carve_flow(nullptr, fw, B, num_steps, false, true).bytes;
     const size_t b = carve_dec(nullptr, dw, B).bytes;
     return lat + (a > b ? a : b);
 }
@@ -441,9 +471,11 @@ static int generate_actions_run(const float* obs_w, const float* obs_b, int32_t 
         SplitkScope sk(rest, tl_skb);   // the first tl_skb bytes of either carve below
         VITA_TRY(gemm_f32(lin(obs_features, ldobs, obs_w, O, obs_b, lat, D, B, D, O, VITA_ACT_NONE), s));  // vita_policy.py:194
     }
-    VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s));                           // :196-203
+    bool dec_done = false;
+    VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s, dw, actions, lda, &dec_done));   // :196-203
     if (latents_out)
         VITA_CHECK_HIP(hipMemcpyAsync(latents_out, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s));
+    if (dec_done) return VITA_OK;                                                                       // serving batches: :206 ran in the same launch
     return decoder_forward(dw, lat, D, actions, lda, B, rest, s);                                       // :206
 }
 
@@ -487,6 +519,7 @@ int vita_generate_actions_noalloc_f32(const float* obs_w, const float* obs_b, in
     }
     void* ws = nullptr;
     VITA_TRY(noalloc_scratch(&ws, who));
+    struct SymbolScope { SymbolScope() { tl_ws_symbol = true; } ~SymbolScope() { tl_ws_symbol = false; } } sym;
     return generate_actions_run(obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, latents_out, B, num_steps, ws,
                                 (hipStream_t)stream);
 }

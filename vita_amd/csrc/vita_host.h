@@ -26,7 +26,17 @@ bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* 
 size_t ode_persistent_sync_bytes(int K, int L);
 int set_ode_persistent(int on);   // returns the previous setting
 void set_ode_persistent_stamps(void* device_buf);
+void* ode_persistent_stamps();
 size_t ode_persistent_status_offset();
+bool ode_persistent_enabled();     // the process-wide switch (VITA_NO_PERSISTENT / vita_ode_sample_set_persistent)
+// the weights-resident Euler sampler for serving batches (vita_ode_resident.hip): one launch, weights in LDS for all K steps
+bool ode_resident_dims(const vita_flownet_weights* w, int B);
+bool ode_resident_eligible(const vita_flownet_weights* w, int B, const float* x0, int64_t ldx0, const float* x_out, int64_t ldo);
+int launch_ode_resident(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
+                        float dt, float* h, float* u, float* xi, const float* mod, void* sync, bool acquire, hipStream_t s,
+                        const vita_decoder_weights* dw = nullptr, float* da = nullptr, float* db = nullptr, float* actions = nullptr,
+                        int64_t lda = 0);
+bool ode_resident_decoder_ok(const vita_decoder_weights* dw, const float* actions, int64_t lda);
 int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
                           float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,
                           const float* c1f, const float* c2f, void* sync, hipStream_t s);

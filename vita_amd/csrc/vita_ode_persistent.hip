@@ -35,13 +35,9 @@
 #define VITA_EPI_STAMP(i)
 #include "vita_gemm_dma_tile.h"
 #include "vita_host.h"
+#include "vita_ode_sync.h"
 
 namespace vita {
-
-constexpr int kTeamStride = 32;          // counters 128 bytes apart
-constexpr int kMaxTeams = 64;
-constexpr int kSyncWords = kTeamStride * (kMaxTeams + 1);   // + the timeout word's line (zeroed before every launch)
-constexpr int kStickyWord = kSyncWords;                      // first timeout code of the whole call (zeroed once per call)
 
 struct OdeParams {
     vita_flownet_weights w;
@@ -60,17 +56,6 @@ struct OdeParams {
     uint16_t *xb_mid, *xb_final; // bf16 state written by steps 0..K-2 / by the last step
     uint16_t *hnb, *ub;          // bf16 h * mul and u
 };
-
-__device__ __forceinline__ unsigned long long clock64_shader() {   // shader clock (follows DVFS)
-    unsigned long long t;
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
-__device__ __forceinline__ unsigned long long clock64_real() {     // 100 MHz constant clock
-    unsigned long long t;
-    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
-    return t;
-}
 
 // the consumer half of the hand-off; run by all threads between the weight prefetch and the first dependent load
 struct TeamSync {
@@ -275,8 +260,10 @@ static bool persistent_disabled() {
     }
     return v == 0;
 }
+bool ode_persistent_enabled() { return !persistent_disabled(); }
 static std::atomic<unsigned long long*> g_stamps{nullptr};
 void set_ode_persistent_stamps(void* device_buf) { g_stamps.store(static_cast<unsigned long long*>(device_buf)); }
+void* ode_persistent_stamps() { return g_stamps.load(); }
 int set_ode_persistent(int on) {
     const bool was_off = persistent_disabled();
     g_persistent.store(on ? 1 : 0, std::memory_order_relaxed);
@@ -284,7 +271,7 @@ int set_ode_persistent(int on) {
 }
 
 // hand-off words, then the phase table of a solve with up to `K` steps and `L` layers
-static size_t sync_words_bytes() { return (size_t)(kSyncWords + kTeamStride) * sizeof(unsigned); }
+static size_t sync_words_bytes() { return ode_sync_words_bytes(); }
 size_t ode_persistent_sync_bytes(int K, int L) { return ((sync_words_bytes() + 255) & ~size_t(255)) + (size_t)K * (2 + 2 * L) * sizeof(PhaseDesc); }
 size_t ode_persistent_status_offset() { return (size_t)kStickyWord * sizeof(unsigned); }
 
