@@ -16,7 +16,9 @@ sd = make_state_dict(533, 21, seed=0)
 fw = ops.FlowNetHandle(sd, dev)
 x0 = torch.randn(B, 512, generator=torch.Generator().manual_seed(1)).to(dev)
 PH = 2 + 2 * L
-buf = torch.zeros(256 * K * PH * 6, dtype=torch.int64, device=dev)
+TP = 3      # time-path phases ahead of the steps (K <= 32, TE = 256)
+NPH = K * PH + TP
+buf = torch.zeros(256 * NPH * 6, dtype=torch.int64, device=dev)
 lib = _lib.load()
 for _ in range(3):
     ops.ode_sample(fw, x0, K)
@@ -24,10 +26,11 @@ lib.vita_debug_ode_stamps(buf.data_ptr())
 ops.ode_sample(fw, x0, K)
 torch.cuda.synchronize()
 lib.vita_debug_ode_stamps(None)
-s = buf.cpu().view(256, K * PH, 6).double() / 100.0     # microseconds
+s = buf.cpu().view(256, NPH, 6).double() / 100.0     # microseconds
 kinds = {"in_proj": [], "fc1": [], "fc2": [], "out_proj": []}
-for p in range(1, K * PH):
-    ph = p % PH
+kinds["time_path"] = [1, 2]
+for p in range(TP, NPH):
+    ph = (p - TP) % PH
     kinds["in_proj" if ph == 0 else "out_proj" if ph == PH - 1 else ("fc1" if (ph - 1) % 2 == 0 else "fc2")].append(p)
 out = {"B": B, "total_us": float(s[:, -1, 4].max() - s[:, 0, 0].min()), "first_phase_start_spread_us": float(s[:, 0, 0].max() - s[:, 0, 0].min())}
 for kind, ps in kinds.items():

@@ -40,6 +40,7 @@ struct FlowWs {
     float* sync;                         // hand-off state of the persistent sampler (team counters, timeout / status words)
     float* xi;                           // weights-resident sampler: the Euler state in the blocked hand-off layout
     float *da, *db;                      // ... and the decoder's activations when it rides behind the last step
+    float *thid, *tsilu;                 // ... and the time path's, when it runs in the same launch
     size_t bytes;
 };
 
@@ -68,12 +69,14 @@ static FlowWs carve_flow(void* ws, const vita_flownet_weights* w, int B, int T, 
     f.hn = c.take((size_t)B * w->H);
     f.u = c.take(Bp * w->FF);
     f.x = need_x ? c.take((size_t)B * w->D) : nullptr;
-    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = f.sync = f.xi = f.da = f.db = nullptr;
+    f.stat = f.c1 = f.c2 = f.c1f = f.c2f = f.sync = f.xi = f.da = f.db = f.thid = f.tsilu = nullptr;
     if (sampling && ode_resident_dims(w, B)) {
         f.sync = c.take(ode_persistent_sync_bytes(0, 0) / sizeof(float));   // hand-off words only
         f.xi = c.take(Bp * w->D);
         f.da = c.take(Bp * w->D);        // decoder hidden width == D on that path (ode_resident_decoder_ok)
         f.db = c.take(Bp * w->D);
+        f.thid = c.take((size_t)32 * 4 * w->TE);
+        f.tsilu = c.take((size_t)32 * w->H);
     }
     if (sampling && use_ln_fold(w, B)) {   // sampling only (per-row t has per-row modulation: no shared tables)
         f.sync = c.take(ode_persistent_sync_bytes(T, w->L) / sizeof(float));
@@ -190,32 +193,38 @@ static int flow_eval_folded(const vita_flownet_weights* w, const FlowWs& f, cons
 // *dec_done says whether it did (otherwise the caller runs decoder_forward).
 static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, int B, int K,
                       float* traj, void* ws, hipStream_t s, const vita_decoder_weights* dec = nullptr, float* actions = nullptr,
-                      int64_t lda = 0, bool* dec_done = nullptr) {
+                      int64_t lda = 0, bool* dec_done = nullptr, const ResidentObs* obs = nullptr) {
     const int D = w->D, H = w->H, L = w->L;
     FlowWs f = carve_flow(ws, w, B, K, false, true);
     SplitkScope sk(f.sk, tl_skb);
-    VITA_TRY(launch_step_times(f.ts, K, s));
-    VITA_TRY(time_path(w, f, K, s));
-    const bool fold = f.stat != nullptr;
-    if (fold) VITA_TRY(fold_tables(w, f, K, s));
     const float dt = (float)(1.0 / (double)K);  // python float 1.0/num_steps, rounded to fp32 at the multiply
     if (traj)
         VITA_CHECK_HIP(hipMemcpy2DAsync(traj, (size_t)D * 4, x0, (size_t)ldx0 * 4, (size_t)D * 4, (size_t)B, hipMemcpyDeviceToDevice, s));
-    if (fold && ode_persistent_eligible(w, B, x0, ldx0, x_out, ldo)) {
-        // all K steps in one persistent launch (vita_ode_persistent.hip): same tiles, same epilogues, same bits
-        VITA_TRY(launch_ode_persistent(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.hn, f.u, f.stat, f.mod, f.c1, f.c2, f.c1f, f.c2f,
-                                       f.sync, s));
+    if (f.sync && f.xi && ode_resident_eligible(w, B, x0, ldx0, x_out, ldo)) {
+        // serving batches: one launch, the net's weights resident in LDS for all K steps (vita_ode_resident.hip); the time
+        // path and the decoder ride in the same launch where their shapes allow
+        const bool tp = ode_resident_time_path(w, K);
+        if (!tp) {
+            VITA_TRY(launch_step_times(f.ts, K, s));
+            VITA_TRY(time_path(w, f, K, s));
+        }
+        const bool fuse_dec = dec != nullptr && dec->D == w->D && ode_resident_decoder_ok(dec, actions, lda);
+        VITA_TRY(launch_ode_resident(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.u, f.xi, f.mod, tp ? f.thid : nullptr,
+                                     tp ? f.tsilu : nullptr, f.sync, tl_ws_symbol, s, fuse_dec ? dec : nullptr, f.da, f.db, actions, lda, obs));
+        if (dec_done) *dec_done = fuse_dec;
         if (traj)
             VITA_CHECK_HIP(hipMemcpy2DAsync(x_out, (size_t)ldo * 4, traj + (size_t)K * B * D, (size_t)D * 4, (size_t)D * 4, (size_t)B,
                                             hipMemcpyDeviceToDevice, s));
         return VITA_OK;
     }
-    if (f.sync && ode_resident_eligible(w, B, x0, ldx0, x_out, ldo)) {
-        // serving batches: one launch, the net's weights resident in LDS for all K steps (vita_ode_resident.hip)
-        const bool fuse_dec = dec != nullptr && dec->D == w->D && ode_resident_decoder_ok(dec, actions, lda);
-        VITA_TRY(launch_ode_resident(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.u, f.xi, f.mod, f.sync, tl_ws_symbol, s,
-                                     fuse_dec ? dec : nullptr, f.da, f.db, actions, lda));
-        if (dec_done) *dec_done = fuse_dec;
+    VITA_TRY(launch_step_times(f.ts, K, s));
+    VITA_TRY(time_path(w, f, K, s));
+    const bool fold = f.stat != nullptr;
+    if (fold) VITA_TRY(fold_tables(w, f, K, s));
+    if (fold && ode_persistent_eligible(w, B, x0, ldx0, x_out, ldo)) {
+        // all K steps in one persistent launch (vita_ode_persistent.hip): same tiles, same epilogues, same bits
+        VITA_TRY(launch_ode_persistent(w, x0, ldx0, x_out, ldo, traj, B, K, dt, f.h, f.hn, f.u, f.stat, f.mod, f.c1, f.c2, f.c1f, f.c2f,
+                                       f.sync, s));
         if (traj)
             VITA_CHECK_HIP(hipMemcpy2DAsync(x_out, (size_t)ldo * 4, traj + (size_t)K * B * D, (size_t)D * 4, (size_t)D * 4, (size_t)B,
                                             hipMemcpyDeviceToDevice, s));
@@ -467,12 +476,16 @@ static int generate_actions_run(const float* obs_w, const float* obs_b, int32_t 
     const int D = fw->D;
     float* lat = static_cast<float*>(workspace);
     char* rest = static_cast<char*>(workspace) + (((size_t)B * D * 4 + 255) & ~size_t(255));
-    {
+    // serving batches: obs_encoder, the solve and the decoder are one launch (vita_ode_resident.hip); the condition is the one
+    // ode_sample evaluates
+    const ResidentObs oe{obs_w, obs_b, obs_features, ldobs, O};
+    const bool fuse_obs = O <= 1024 && ode_resident_eligible(fw, B, lat, D, lat, D);
+    if (!fuse_obs) {
         SplitkScope sk(rest, tl_skb);   // the first tl_skb bytes of either carve below
         VITA_TRY(gemm_f32(lin(obs_features, ldobs, obs_w, O, obs_b, lat, D, B, D, O, VITA_ACT_NONE), s));  // vita_policy.py:194
     }
     bool dec_done = false;
-    VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s, dw, actions, lda, &dec_done));   // :196-203
+    VITA_TRY(ode_sample(fw, lat, D, lat, D, B, num_steps, nullptr, rest, s, dw, actions, lda, &dec_done, fuse_obs ? &oe : nullptr));   // :196-203
     if (latents_out)
         VITA_CHECK_HIP(hipMemcpyAsync(latents_out, lat, (size_t)B * D * 4, hipMemcpyDeviceToDevice, s));
     if (dec_done) return VITA_OK;                                                                       // serving batches: :206 ran in the same launch

@@ -32,10 +32,12 @@ bool ode_persistent_enabled();     // the process-wide switch (VITA_NO_PERSISTEN
 // the weights-resident Euler sampler for serving batches (vita_ode_resident.hip): one launch, weights in LDS for all K steps
 bool ode_resident_dims(const vita_flownet_weights* w, int B);
 bool ode_resident_eligible(const vita_flownet_weights* w, int B, const float* x0, int64_t ldx0, const float* x_out, int64_t ldo);
+struct ResidentObs { const float *w, *b, *x; int64_t ldx; int O; };     // obs_encoder ahead of the first step (O <= 1024)
 int launch_ode_resident(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
-                        float dt, float* h, float* u, float* xi, const float* mod, void* sync, bool acquire, hipStream_t s,
+                        float dt, float* h, float* u, float* xi, float* mod, float* thid, float* tsilu, void* sync, bool acquire, hipStream_t s,
                         const vita_decoder_weights* dw = nullptr, float* da = nullptr, float* db = nullptr, float* actions = nullptr,
-                        int64_t lda = 0);
+                        int64_t lda = 0, const ResidentObs* obs = nullptr);
+bool ode_resident_time_path(const vita_flownet_weights* w, int K);
 bool ode_resident_decoder_ok(const vita_decoder_weights* dw, const float* actions, int64_t lda);
 int launch_ode_persistent(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
                           float dt, float* h, float* hn, float* u, float* stat, const float* mod, const float* c1, const float* c2,

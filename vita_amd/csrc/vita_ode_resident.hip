@@ -57,7 +57,9 @@ struct ResidentArgs {
     float* x_out; int64_t ldo;           // every step writes it (in place from step 1 on) unless traj
     float* traj;                         // NULL or (K+1, B, D): step k reads slab k, writes slab k+1
     float *h, *u, *xi;                   // hand-off buffers h (B, H), u (B, FF), x (B, D), blocked: rows padded to a multiple of 4
-    const float* mod;                    // (K, L, 3H): gamma | scale | shift per layer and step (time path)
+    float* mod;                          // (K, L, 3H): gamma | scale | shift per layer and step (time path)
+    int tp;                              // != 0: the time path runs in this launch too (K <= 32, TE = 256); scratch below, blocked
+    float *thid, *tsilu;                 // (K, 4 TE), (K, H)
     unsigned* sync;
     int B, K;
     float dt;
@@ -68,6 +70,9 @@ struct ResidentArgs {
     vita_decoder_weights dw;
     float *da, *db;                      // blocked hand-off buffers (B, HD)
     float* actions; int64_t lda;         // (B, OUT) row-major
+    // the observation encoder ahead of the first step (obs_encoder = nn.Linear(O, D), vita_policy.py:77,194): obs_w != NULL;
+    // then x0 is not read
+    const float *obs_w, *obs_b, *obs; int64_t ldobs; int O;
     unsigned long long* stamps;   // diagnostic: NULL, or [workgroup][phase][6] 100 MHz clocks: phase start, wait over, A landed, sums in LDS, published
 };
 
@@ -119,6 +124,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t rs_rsrc(const void* base, unsi
 __device__ __forceinline__ f32x4 load16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16));
 }
+__device__ __forceinline__ float load4_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, 16));
+}
 __device__ __forceinline__ void store16_sc1(__amdgpu_buffer_rsrc_t r, unsigned byte_off, const f32x4& v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_r, v), r, (int)byte_off, 0, 16);
 }
@@ -139,58 +147,93 @@ __device__ __forceinline__ float kq_sum(float v) {
     return v;
 }
 
+// What one phase multiplies.
+struct PhaseIn {
+    __amdgpu_buffer_rsrc_t ra;            // A operand (ASRC 0: blocked hand-off buffer; 1: the caller's row-major x0)
+    unsigned lda_bytes;                   // ASRC 1: row stride
+    int steps;                            // ASRC 2: A = the sinusoidal embedding of t_k = k / steps, row k < steps (pos_embed.py:11-18)
+    const float* wl;                      // the weight slice in LDS, column c at wl + c * (KDIM + 16); GW: the (N, KDIM) matrix in global memory
+    int gw_col0, gw_n;                    // GW: this workgroup's first column, and N (columns >= N read as zeros)
+    __amdgpu_buffer_rsrc_t rln;           // LNM 1: the modulation table, (1 + mul) and add at these byte offsets (sc1 loads: the time
+    unsigned ln_mul_off, ln_add_off;      //        path of this very launch may have written it)
+    const float *ln_w, *ln_b;             // LNM 2: nn.LayerNorm's affine vectors (weights: plain loads)
+};
+
 // One GEMM of the chain on this workgroup's column slice: out[row][c] = sum_k A'[row][k] * W[c][k] for row < 32,
-// c < 4 * CG, with A' = A (LNM = 0), LN(A) * (1 + mul) + add (LNM = 1, eps 1e-6) or LN(A) * mul + add (LNM = 2, eps 1e-5).
-//   NCH : K = 512 * NCH (each wave owns 64 * NCH consecutive k)
-//   wl  : the slice in LDS, column c at wl + c * KP
+// c < 4 * CG, with A' = A (LNM = 0), LN(A) * (1 + mul) + add (LNM = 1, eps 1e-6) or LN(A) * w + b (LNM = 2, eps 1e-5).
+//   KDIM : the reduction length (256, 512, 1024, 2048); each of the 8 waves owns KDIM / 8 consecutive k
+//   GW   : the weights are read from global memory into registers BEFORE the hand-off wait -- they depend on nobody, so
+//          their latency hides behind the wait; for matrices used once per solve (time path, decoder), which LDS has no room for
 // On return red[w][row][8] holds wave w's partial sums (behind a workgroup barrier); false = the hand-off wait ran out.
-//   ROWMAJ : A is the caller's row-major x0 (first phase of a solve); otherwise one of the blocked hand-off buffers
-//   GW     : the weights are read from global memory (wl = row 0 of the (N, K) matrix, this workgroup's columns start at
-//            gw_col0; columns >= gw_n read as zeros) into registers BEFORE the hand-off wait -- they depend on nobody, so
-//            their latency hides behind the wait; for matrices used once per solve (the decoder), which LDS has no room for
-template <int NCH, int CG, int LNM, bool ROWMAJ = false, bool GW = false>
-__device__ __forceinline__ bool rs_phase(__amdgpu_buffer_rsrc_t ra, unsigned lda_bytes, const float* wl, int gw_col0, int gw_n,
-                                         const float* __restrict__ ln_mul,
-                                         const float* __restrict__ ln_add, float* red, float* st, const GridSync& sy,
-                                         unsigned long long* stamp) {
-    constexpr int KP = NCH == 1 ? RS_KP1 : RS_KP2;
-    constexpr int NS = 4 * NCH;                  // 16-k pieces of this wave's k range
+template <int KDIM, int CG, int LNM, int ASRC, bool GW>
+__device__ __forceinline__ bool rs_phase(const PhaseIn& in, float* red, float* st, const GridSync& sy, unsigned long long* stamp) {
+    constexpr int KP = KDIM + 16;
+    constexpr int NS = KDIM / 128;               // 16-k pieces of this wave's k range
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 3, kq = (lane >> 2) & 3, rq = lane >> 4;
-    const int kb = w * (64 * NCH) + 4 * kq;      // + 16 * s
-    f32x4 lm[LNM ? 4 : 1], la[LNM ? 4 : 1];
-    if constexpr (LNM != 0) {                    // modulation / affine vectors: written by earlier launches, plain loads
-        static_assert(NCH == 1, "LayerNorm phases have K = H");
+    const int kb = w * (KDIM / 8) + 4 * kq;      // + 16 * s
+    f32x4 lm[LNM ? NS : 1], la[LNM ? NS : 1];
+    if constexpr (LNM != 0) {
+        static_assert(LNM == 0 || KDIM == RS_D, "LayerNorm phases have K = H");
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            lm[s] = *reinterpret_cast<const f32x4*>(ln_mul + kb + 16 * s);
-            if constexpr (LNM == 1) lm[s] += 1.0f;
-            la[s] = *reinterpret_cast<const f32x4*>(ln_add + kb + 16 * s);
+        for (int s = 0; s < NS; ++s) {
+            if constexpr (LNM == 1) {
+                lm[s] = load16_sc1(in.rln, in.ln_mul_off + (unsigned)(kb + 16 * s) * 4u) + 1.0f;
+                la[s] = load16_sc1(in.rln, in.ln_add_off + (unsigned)(kb + 16 * s) * 4u);
+            } else {
+                lm[s] = *reinterpret_cast<const f32x4*>(in.ln_w + kb + 16 * s);
+                la[s] = *reinterpret_cast<const f32x4*>(in.ln_b + kb + 16 * s);
+            }
         }
     }
     f32x4 wreg[GW ? CG : 1][GW ? NS : 1];
     if constexpr (GW) {
-        constexpr unsigned KB = 512u * NCH * 4u;      // bytes per weight row
-        const __amdgpu_buffer_rsrc_t rw = rs_rsrc(wl, (unsigned)gw_n * KB);
+        constexpr unsigned KB = (unsigned)KDIM * 4u;      // bytes per weight row
+        const __amdgpu_buffer_rsrc_t rw = rs_rsrc(in.wl, (unsigned)in.gw_n * KB);
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg)
 #pragma unroll
             for (int s = 0; s < NS; ++s)
-                wreg[cg][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rw, (int)((unsigned)(gw_col0 + 4 * cg + i) * KB + (unsigned)(kb + 16 * s) * 4u), 0, 0));
+                wreg[cg][s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                            rw, (int)((unsigned)(in.gw_col0 + 4 * cg + i) * KB + (unsigned)(kb + 16 * s) * 4u), 0, 0));
+    }
+    f32x4 a[2][NS];
+    if constexpr (ASRC == 2) {       // sinusoidal embedding, the arithmetic of sinusoid_kernel (vita_elementwise.hip); waves 0-3 hold the
+                                     // sines, 4-7 the cosines (KDIM = 2 * half, a wave's k range lies in one half)
+        constexpr int half = KDIM / 2;
+        const float emb = logf(10000.0f) / (float)(half - 1);
+#pragma unroll
+        for (int R = 0; R < 2; ++R) {
+            const int row = 16 * R + 4 * rq + i;
+            const float t = (float)((double)row / (double)in.steps);      // flow_matchers.py:69
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                a[R][s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (16 * R < in.steps && row < in.steps) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int k = kb + 16 * s + r;
+                        const float e = t * expf((float)(k & (half - 1)) * -emb);
+                        a[R][s][r] = (w < RS_NW / 2) ? sinf(e) : cosf(e);
+                    }
+                }
+            }
+        }
     }
     if (!sy()) return false;
     if (stamp && tid == 0) stamp[1] = clock64_real();
-    f32x4 a[2][NS];
+    if constexpr (ASRC != 2) {
 #pragma unroll
-    for (int R = 0; R < 2; ++R) {
-        if constexpr (ROWMAJ) {
-            const unsigned off = (unsigned)(16 * R + 4 * rq + i) * lda_bytes + (unsigned)kb * 4u;
+        for (int R = 0; R < 2; ++R) {
+            if constexpr (ASRC == 1) {
+                const unsigned off = (unsigned)(16 * R + 4 * rq + i) * in.lda_bytes + (unsigned)kb * 4u;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) a[R][s] = load16_sc1(ra, off + 64u * s);
-        } else {      // block (row group 4 R + rq, k chunk kb / 4 + 4 s): 64 bytes, this lane's row at + 16 i
-            const unsigned off = ((unsigned)(4 * R + rq) * (128u * NCH) + (unsigned)(kb >> 2)) * 64u + 16u * i;
+                for (int s = 0; s < NS; ++s) a[R][s] = load16_sc1(in.ra, off + 64u * s);
+            } else {      // block (row group 4 R + rq, k chunk kb / 4 + 4 s): 64 bytes, this lane's row at + 16 i
+                const unsigned off = ((unsigned)(4 * R + rq) * (unsigned)(KDIM / 4) + (unsigned)(kb >> 2)) * 64u + 16u * i;
 #pragma unroll
-            for (int s = 0; s < NS; ++s) a[R][s] = load16_sc1(ra, off + 256u * s);
+                for (int s = 0; s < NS; ++s) a[R][s] = load16_sc1(in.ra, off + 256u * s);
+            }
         }
     }
     if (stamp) {
@@ -199,7 +242,7 @@ __device__ __forceinline__ bool rs_phase(__amdgpu_buffer_rsrc_t ra, unsigned lda
     }
     if constexpr (LNM != 0) {
         // two-pass statistics; written on whole f32x4 values so that the packed fp32 instructions (v_pk_add / mul / fma_f32)
-        // carry them: with two waves per SIMD this block is bound by the number of VALU instructions
+        // carry them
         constexpr float inv_n = 1.0f / (float)RS_D;
         const float eps = LNM == 1 ? 1e-6f : 1e-5f;
         float p[2];
@@ -241,12 +284,12 @@ __device__ __forceinline__ bool rs_phase(__amdgpu_buffer_rsrc_t ra, unsigned lda
 #pragma unroll
             for (int ww = 0; ww < RS_NW; ++ww) t += st2[ww * RS_ROWS + 16 * R + 4 * rq + i];
             const float var = t * inv_n + eps;
-            float rstd = __builtin_amdgcn_rsqf(var);                 // 1 ulp; one Newton step makes it correctly rounded to < 1 ulp
+            float rstd = __builtin_amdgcn_rsqf(var);                 // 1 ulp; one Newton step on top
             rstd = rstd * (1.5f - 0.5f * var * rstd * rstd);
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 f32x4 y = a[R][s] * rstd;
-                y = y * lm[s] + la[s];       // LNM = 1: lm = 1 + scale (simple_flow_net.py:44-45); LNM = 2: nn.LayerNorm's weight (:81,106)
+                y = y * lm[s] + la[s];       // LNM 1: lm = 1 + scale (simple_flow_net.py:44-45); LNM 2: nn.LayerNorm's weight (:81,106)
                 a[R][s] = y;
             }
         }
@@ -263,7 +306,7 @@ __device__ __forceinline__ bool rs_phase(__amdgpu_buffer_rsrc_t ra, unsigned lda
 #pragma unroll
         for (int cg = 0; cg < CG; ++cg) {
             if constexpr (GW) wv[cg] = wreg[cg][s];
-            else wv[cg] = *reinterpret_cast<const f32x4*>(wl + (4 * cg + i) * KP + kb + 16 * s);
+            else wv[cg] = *reinterpret_cast<const f32x4*>(in.wl + (4 * cg + i) * KP + kb + 16 * s);
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -286,6 +329,48 @@ __device__ __forceinline__ bool rs_phase(__amdgpu_buffer_rsrc_t ra, unsigned lda
     __syncthreads();
     if (stamp && tid == 0) stamp[3] = clock64_real();
     return true;
+}
+
+// The observation encoder's GEMM: A (nrows, Kact) and W (N, Kact) row-major with Kact not a multiple of 4 and rows that are not
+// 16-byte aligned (O = 533: 512 camera features + 21 joint positions), so both operands are read dword by dword.  Nothing of it is
+// written in this launch: plain loads, no wait.  Same lane layout and `red` result as rs_phase<1024, 1, ...>.
+__device__ __forceinline__ void rs_phase_unaligned(const float* __restrict__ A, int64_t lda, int nrows, int Kact, const float* __restrict__ W,
+                                                   int col0, int N, float* red) {
+    constexpr int KDIM = 1024, NS = KDIM / 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int i = lane & 3, kq = (lane >> 2) & 3, rq = lane >> 4;
+    const int kb = w * (KDIM / 8) + 4 * kq;
+    f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    const int col = col0 + i;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        if (w * (KDIM / 8) + 16 * s >= Kact) break;          // wave-uniform: this 16-k piece lies past the operands' end
+        f32x4 a[2], wv;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int k = kb + 16 * s + r;
+            const bool kin = k < Kact;
+            wv[r] = (kin && col < N) ? W[(int64_t)col * Kact + k] : 0.f;
+#pragma unroll
+            for (int R = 0; R < 2; ++R) {
+                const int row = 16 * R + 4 * rq + i;
+                a[R][r] = (kin && row < nrows) ? A[(int64_t)row * lda + k] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int R = 0; R < 2; ++R) acc[R] = __builtin_amdgcn_mfma_f32_4x4x1f32(a[R][r], wv[r], acc[R], 0, 0, 0);
+    }
+#pragma unroll
+    for (int R = 0; R < 2; ++R) {
+        f32x4 c = acc[R];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c[v] = kq_sum(c[v]);
+        const float val = kq == 0 ? c[0] : kq == 1 ? c[1] : kq == 2 ? c[2] : c[3];
+        red[(w * RS_ROWS + 16 * R + 4 * rq + kq) * 8 + i] = val;
+    }
+    __syncthreads();
 }
 
 // sum of the 8 waves' partials, in wave order
@@ -338,14 +423,14 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
     {
         const float* xs0 = q.traj ? q.traj : q.x0;
         const int64_t ld0 = q.traj ? D : q.ldx0;
-        if (mine) { x0v = xs0[(int64_t)row * ld0 + col2]; x1v = xs0[(int64_t)row * ld0 + col2 + 1]; }
+        if (mine && q.obs_w == nullptr) { x0v = xs0[(int64_t)row * ld0 + col2]; x1v = xs0[(int64_t)row * ld0 + col2 + 1]; }
     }
     const unsigned rgs = (unsigned)(B + 3) >> 2;              // row groups that hold a row < B: loads past them return zeros
     const __amdgpu_buffer_rsrc_t rh = rs_rsrc(q.h, rgs * H * 16u), ru = rs_rsrc(q.u, rgs * FF * 16u), rxi = rs_rsrc(q.xi, rgs * D * 16u);
     unsigned* my_cnt = q.sync + (blockIdx.x & 7) * kTeamStride;
     GridSync sy{q.sync, 0u, q.spin_limit, 0u, q.acquire, flag};
     unsigned phase = 0;
-    const int nph = q.K * (2 + 2 * L) + (q.dec ? 2 + 2 * q.dw.NL : 0);
+    const int nph = q.K * (2 + 2 * L) + (q.dec ? 2 + 2 * q.dw.NL : 0) + (q.tp ? 3 : 0) + ((q.obs_w && !q.tp) ? 1 : 0);
     unsigned long long* stp = q.stamps ? q.stamps + (size_t)blockIdx.x * nph * 6 : nullptr;
     auto publish = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every wave: its write-through stores have left
@@ -361,8 +446,75 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
         sy.target = (RS_WG / 8) * phase;
         sy.code = phase + 1;
     };
+    const __amdgpu_buffer_rsrc_t rmod = rs_rsrc(q.mod, (unsigned)((size_t)q.K * L * 3 * H * 4));
     __syncthreads();                                          // the slices are in LDS
     if (stp && tid == 0) stp[0] = clock64_real();
+
+    if (q.obs_w != nullptr) {
+        // ---- obs_encoder (vita_policy.py:194): the start of the flow; this workgroup's two columns of it are its x
+        const float b0 = q.obs_b[col2], b1 = q.obs_b[col2 + 1];
+        rs_phase_unaligned(q.obs, q.ldobs, B, q.O, q.obs_w, col2, D, red);
+        if (tid < RS_ROWS) {
+            const f32x4 s = rs_sum4(red, row, 0);
+            x0v = s[0] + b0; x1v = s[1] + b1;
+            if (mine) store8_sc1(rxi, rs_blk(row, col2, D) * 4u, x0v, x1v);
+        }
+        if (!q.tp) publish();        // otherwise the time path's first publish carries these stores too
+        else __syncthreads();        // `red` is rewritten by the next phase
+    }
+    if (q.tp) {
+        // ---- the time path for all K steps (simple_flow_net.py:66-71, 27-30, 41): rows = time steps.  sinusoid -> Linear + Mish ->
+        // Linear (+ SiLU, the only form the modulators consume) -> per-layer modulator Linear into the (K, L, 3H) table
+        const int T = q.K;
+        const unsigned tgs = (unsigned)(T + 3) >> 2;
+        const bool trow = tid < RS_ROWS && row < T;
+        const __amdgpu_buffer_rsrc_t rthid = rs_rsrc(q.thid, tgs * 1024u * 16u), rtsilu = rs_rsrc(q.tsilu, tgs * 512u * 16u);
+        {
+            f32x4 b = {0.f, 0.f, 0.f, 0.f};
+            if (tid < RS_ROWS) b = *reinterpret_cast<const f32x4*>(q.w.te1_b + 4 * c);
+            PhaseIn in{};
+            in.steps = T; in.wl = q.w.te1_w; in.gw_col0 = 4 * c; in.gw_n = 1024;
+            if (!rs_phase<256, 1, 0, 2, true>(in, red, st, sy, stp)) return;
+            if (tid < RS_ROWS) {
+                f32x4 s = rs_sum4(red, row, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s[e] = act_mish(s[e] + b[e]);
+                if (trow) store16_sc1(rthid, rs_blk(row, 4 * c, 1024) * 4u, s);
+            }
+            publish();
+        }
+        {
+            const float b0 = q.w.te3_b[col2], b1 = q.w.te3_b[col2 + 1];
+            PhaseIn in{};
+            in.ra = rthid; in.wl = q.w.te3_w; in.gw_col0 = col2; in.gw_n = 512;
+            if (!rs_phase<1024, 1, 0, 0, true>(in, red, st, sy, stp)) return;
+            if (tid < RS_ROWS) {
+                const f32x4 s = rs_sum4(red, row, 0);
+                if (trow) store8_sc1(rtsilu, rs_blk(row, col2, 512) * 4u, act_silu(s[0] + b0), act_silu(s[1] + b1));
+            }
+            publish();
+        }
+        for (int l = 0; l < L; ++l) {       // 3H = 1536 columns per layer: six per workgroup (two 4-column groups, the last two unused)
+            float b[6];
+#pragma unroll
+            for (int e = 0; e < 6; ++e) b[e] = tid < RS_ROWS ? q.w.mod_b[l][6 * c + e] : 0.f;
+            PhaseIn in{};
+            in.ra = rtsilu; in.wl = q.w.mod_w[l]; in.gw_col0 = 6 * c; in.gw_n = 3 * H;
+            if (!rs_phase<RS_D, 2, 0, 0, true>(in, red, st, sy, stp)) return;
+            sy.target = 0;                   // the layers' modulators all read the same activations: one wait serves them all
+            if (tid < RS_ROWS) {
+                const f32x4 sa = rs_sum4(red, row, 0), sb = rs_sum4(red, row, 4);
+                if (trow) {
+                    const unsigned o = (unsigned)(((size_t)row * L + l) * 3 * H + 6 * c) * 4u;
+                    store8_sc1(rmod, o, sa[0] + b[0], sa[1] + b[1]);
+                    store8_sc1(rmod, o + 8u, sa[2] + b[2], sa[3] + b[3]);
+                    store8_sc1(rmod, o + 16u, sb[0] + b[4], sb[1] + b[5]);
+                }
+            }
+            if (l + 1 < L) __syncthreads();  // `red` is rewritten by the next layer's modulator
+        }
+        publish();
+    }
 
     for (int k = 0; k < q.K; ++k) {
         const float* xs;
@@ -375,15 +527,18 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             xs = k == 0 ? q.x0 : q.x_out; lds_ = k == 0 ? q.ldx0 : q.ldo;
             xd = q.x_out; ldd_ = q.ldo;
         }
-        const float* mod = q.mod + (size_t)k * L * 3 * H;
         // ---- input_proj (simple_flow_net.py:100)
         {
             const float b0 = q.w.in_b[col2], b1 = q.w.in_b[col2 + 1];
-            if (k == 0) {       // the caller's row-major x0
-                const __amdgpu_buffer_rsrc_t rx = rs_rsrc(xs, (unsigned)(((int64_t)(B - 1) * lds_ + D) * 4));
-                if (!rs_phase<1, 1, 0, true>(rx, (unsigned)lds_ * 4u, w_in, 0, 0, nullptr, nullptr, red, st, sy, stp)) return;
+            PhaseIn in{};
+            in.wl = w_in;
+            if (k == 0 && q.obs_w == nullptr) {       // the caller's row-major x0
+                in.ra = rs_rsrc(xs, (unsigned)(((int64_t)(B - 1) * lds_ + D) * 4));
+                in.lda_bytes = (unsigned)lds_ * 4u;
+                if (!rs_phase<RS_D, 1, 0, 1, false>(in, red, st, sy, stp)) return;
             } else {
-                if (!rs_phase<1, 1, 0>(rxi, 0u, w_in, 0, 0, nullptr, nullptr, red, st, sy, stp)) return;
+                in.ra = rxi;
+                if (!rs_phase<RS_D, 1, 0, 0, false>(in, red, st, sy, stp)) return;
             }
             if (tid < RS_ROWS) {
                 const f32x4 s = rs_sum4(red, row, 0);
@@ -393,13 +548,16 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             publish();
         }
         for (int l = 0; l < L; ++l) {
-            const float* gamma = mod + (size_t)l * 3 * H;
+            const unsigned gamma_off = (unsigned)(((size_t)k * L + l) * 3 * H) * 4u;     // byte offset of (gamma | scale | shift) in the table
             // ---- fc1 + tanh-GELU on LN(h) * (1 + scale) + shift (:44-45, 19-24): 8 columns, thread (row, half) stores 4
             {
                 const int r8 = tid >> 1, c4 = (tid & 1) * 4;
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
                 if (tid < 2 * RS_ROWS) b = *reinterpret_cast<const f32x4*>(q.w.fc1_b[l] + 8 * c + c4);
-                if (!rs_phase<1, 2, 1>(rh, 0u, w_fc1 + (size_t)l * 8 * RS_KP1, 0, 0, gamma + H, gamma + 2 * H, red, st, sy, stp)) return;
+                PhaseIn in{};
+                in.ra = rh; in.wl = w_fc1 + (size_t)l * 8 * RS_KP1;
+                in.rln = rmod; in.ln_mul_off = gamma_off + H * 4u; in.ln_add_off = gamma_off + 2 * H * 4u;
+                if (!rs_phase<RS_D, 2, 1, 0, false>(in, red, st, sy, stp)) return;
                 if (tid < 2 * RS_ROWS) {
                     f32x4 s = rs_sum4(red, r8, c4);
 #pragma unroll
@@ -411,8 +569,10 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             // ---- fc2, gate, residual (:46): h += gamma * fc2(u)
             {
                 const float b0 = q.w.fc2_b[l][col2], b1 = q.w.fc2_b[l][col2 + 1];
-                const float g0 = gamma[col2], g1 = gamma[col2 + 1];
-                if (!rs_phase<4, 1, 0>(ru, 0u, w_fc2 + (size_t)l * 2 * RS_KP2, 0, 0, nullptr, nullptr, red, st, sy, stp)) return;
+                const float g0 = load4_sc1(rmod, gamma_off + (unsigned)col2 * 4u), g1 = load4_sc1(rmod, gamma_off + (unsigned)col2 * 4u + 4u);
+                PhaseIn in{};
+                in.ra = ru; in.wl = w_fc2 + (size_t)l * 2 * RS_KP2;
+                if (!rs_phase<RS_FF, 1, 0, 0, false>(in, red, st, sy, stp)) return;
                 if (tid < RS_ROWS) {
                     const f32x4 s = rs_sum4(red, row, 0);
                     const float v0 = (s[0] + b0) * g0, v1 = (s[1] + b1) * g1;
@@ -425,7 +585,9 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
         // ---- final LayerNorm (affine) + out_proj + the Euler update x + v * dt (:106-107, flow_matchers.py:71)
         {
             const float b0 = q.w.out_b[col2], b1 = q.w.out_b[col2 + 1];
-            if (!rs_phase<1, 1, 2>(rh, 0u, w_out, 0, 0, q.w.norm_w, q.w.norm_b, red, st, sy, stp)) return;
+            PhaseIn in{};
+            in.ra = rh; in.wl = w_out; in.ln_w = q.w.norm_w; in.ln_b = q.w.norm_b;
+            if (!rs_phase<RS_D, 1, 2, 0, false>(in, red, st, sy, stp)) return;
             if (tid < RS_ROWS) {
                 const f32x4 s = rs_sum4(red, row, 0);
                 const float v0 = (s[0] + b0) * q.dt, v1 = (s[1] + b1) * q.dt;
@@ -449,7 +611,9 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
         const __amdgpu_buffer_rsrc_t rda = rs_rsrc(q.da, rgs * 512u * 16u), rdb = rs_rsrc(q.db, rgs * 512u * 16u);
         {
             const float b0 = dw.in_b[col2], b1 = dw.in_b[col2 + 1];
-            if (!rs_phase<1, 1, 0, false, true>(rxi, 0u, dw.in_w, col2, 512, nullptr, nullptr, red, st, sy, stp)) return;
+            PhaseIn in{};
+            in.ra = rxi; in.wl = dw.in_w; in.gw_col0 = col2; in.gw_n = 512;
+            if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
             if (tid < RS_ROWS) {
                 const f32x4 s = rs_sum4(red, row, 0);
                 if (mine) store8_sc1(rda, rs_blk(row, col2, 512) * 4u, s[0] + b0, s[1] + b1);
@@ -459,7 +623,9 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
         for (int l = 0; l < dw.NL; ++l) {
             {
                 const float b0 = dw.fc1_b[l][col2], b1 = dw.fc1_b[l][col2 + 1];
-                if (!rs_phase<1, 1, 0, false, true>(rda, 0u, dw.fc1_w[l], col2, 512, nullptr, nullptr, red, st, sy, stp)) return;
+                PhaseIn in{};
+                in.ra = rda; in.wl = dw.fc1_w[l]; in.gw_col0 = col2; in.gw_n = 512;
+                if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
                 if (tid < RS_ROWS) {
                     const f32x4 s = rs_sum4(red, row, 0);
                     if (mine) store8_sc1(rdb, rs_blk(row, col2, 512) * 4u, act_gelu_erf(s[0] + b0), act_gelu_erf(s[1] + b1));
@@ -468,7 +634,9 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             }
             {
                 const float b0 = dw.fc2_b[l][col2], b1 = dw.fc2_b[l][col2 + 1];
-                if (!rs_phase<1, 1, 0, false, true>(rdb, 0u, dw.fc2_w[l], col2, 512, nullptr, nullptr, red, st, sy, stp)) return;
+                PhaseIn in{};
+                in.ra = rdb; in.wl = dw.fc2_w[l]; in.gw_col0 = col2; in.gw_n = 512;
+                if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
                 if (tid < RS_ROWS) {
                     const f32x4 s = rs_sum4(red, row, 0);
                     if (mine) store8_sc1(rda, rs_blk(row, col2, 512) * 4u, s[0] + b0, s[1] + b1);
@@ -480,7 +648,9 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             const bool have = col2 < dw.OUT;          // OUT is even: a workgroup has both of its columns or none
             float b0 = 0.f, b1 = 0.f;
             if (have) { b0 = dw.out_b[col2]; b1 = dw.out_b[col2 + 1]; }
-            if (!rs_phase<1, 1, 0, false, true>(rda, 0u, dw.out_w, col2, dw.OUT, nullptr, nullptr, red, st, sy, stp)) return;
+            PhaseIn in{};
+            in.ra = rda; in.wl = dw.out_w; in.gw_col0 = col2; in.gw_n = dw.OUT;
+            if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
             if (tid < RS_ROWS && mine && have) {
                 const f32x4 s = rs_sum4(red, row, 0);
                 float* o = q.actions + (int64_t)row * q.lda + col2;       // nobody reads it in this launch: plain stores
@@ -527,20 +697,31 @@ bool ode_resident_decoder_ok(const vita_decoder_weights* dw, const float* action
     return true;
 }
 
-// h, u, xi: ((B + 3) / 4 * 4) x (H, FF, D) floats of scratch; mod (K, L, 3H) already enqueued on `s`; sync = the workspace's hand-off words.
+// Whether the launch can run the time path itself (then the caller enqueues no time-path kernel and passes thid / tsilu).
+bool ode_resident_time_path(const vita_flownet_weights* w, int K) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    if (w->TE != 256 || K < 1 || K > RS_ROWS || !al(w->te1_w) || !al(w->te3_w) || !al(w->te1_b)) return false;
+    for (int l = 0; l < w->L; ++l)
+        if (!al(w->mod_w[l])) return false;
+    return true;
+}
+
+// h, u, xi: ((B + 3) / 4 * 4) x (H, FF, D) floats of scratch; thid / tsilu: 32 x (1024, 512) floats, or NULL with mod (K, L, 3H) already enqueued on `s`; sync = the workspace's hand-off words.
 int launch_ode_resident(const vita_flownet_weights* w, const float* x0, int64_t ldx0, float* x_out, int64_t ldo, float* traj, int B, int K,
-                        float dt, float* h, float* u, float* xi, const float* mod, void* sync, bool acquire, hipStream_t s,
-                        const vita_decoder_weights* dw, float* da, float* db, float* actions, int64_t lda) {
+                        float dt, float* h, float* u, float* xi, float* mod, float* thid, float* tsilu, void* sync, bool acquire, hipStream_t s,
+                        const vita_decoder_weights* dw, float* da, float* db, float* actions, int64_t lda, const ResidentObs* obs) {
     static const bool force_acquire = getenv("VITA_RESIDENT_ACQUIRE") != nullptr && atoi(getenv("VITA_RESIDENT_ACQUIRE")) != 0;
     ResidentArgs a{};
     a.w = *w;
     a.x0 = x0; a.ldx0 = ldx0; a.x_out = x_out; a.ldo = ldo; a.traj = traj;
     a.h = h; a.u = u; a.xi = xi; a.mod = mod;
+    a.tp = thid != nullptr ? 1 : 0; a.thid = thid; a.tsilu = tsilu;
     a.sync = static_cast<unsigned*>(sync);
     a.B = B; a.K = K; a.dt = dt;
     a.spin_limit = 1u << 22;
     a.acquire = (acquire || force_acquire) ? 1 : 0;
     a.stamps = static_cast<unsigned long long*>(ode_persistent_stamps());
+    if (obs != nullptr) { a.obs_w = obs->w; a.obs_b = obs->b; a.obs = obs->x; a.ldobs = obs->ldx; a.O = obs->O; }
     if (dw != nullptr) {      // the decoder rides behind the last step (the caller has checked ode_resident_decoder_ok)
         a.dec = 1; a.dw = *dw; a.da = da; a.db = db; a.actions = actions; a.lda = lda;
     }
