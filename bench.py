@@ -235,6 +235,27 @@ def main():
     persistent = bool(lib.vita_ode_sample_takes_persistent(ctypes.byref(fw.w), B))
     sampler_status = ops.ode_sample_status(fw, B, K, dev)
 
+    # ---- serving-size latency (rank 0): generate_actions at eval_n_envs rows (default_policy.yaml:48), the weights-resident
+    # launch against the per-launch path
+    serving = None
+    if rank == 0 and args.hidden == 512:
+        SB = 25
+        sobs = obs[:SB].contiguous()
+        sout = torch.empty(SB, dw.OUT, device=dev)
+        serving = {"batch": SB, "ode_steps": K, "what": "generate_actions, obs features -> actions, one call per solve, back to back",
+                   "takes_resident_launch": int(lib.vita_ode_sample_takes_persistent(ctypes.byref(fw.w), SB)) == 2}
+        for name, on in (("resident", True), ("per_launch", False)):
+            prev = ops.set_persistent_sampler(on)
+            for _ in range(10):
+                ops.generate_actions(ow, ob, fw, dw, sobs, K, out=sout)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for _ in range(200):
+                ops.generate_actions(ow, ob, fw, dw, sobs, K, out=sout)
+            torch.cuda.synchronize(dev)
+            serving[f"ms_per_solve_{name}"] = round((time.perf_counter() - t0) / 200 * 1e3, 4)
+            ops.set_persistent_sampler(prev)
+
     # ---- bf16-operand variant of the same path (side figure: NOT the headline, the reference is strict fp32)
     bf16 = None
     if rank == 0:
@@ -469,6 +490,7 @@ def main():
             "train_large_batch": train_large,
             "train_large_batch_bf16": train_large_bf16,
             "bf16_variant": bf16,
+            "serving_latency": serving,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

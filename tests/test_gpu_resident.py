@@ -100,3 +100,29 @@ def test_generate_actions_serving_batch(net):
     assert nerr(a, b) <= 2e-6
     ref = O.generate_actions(sd, obs.cpu(), 6, 16, 21)
     assert nerr(a.reshape(25, -1), ref.reshape(25, -1)) <= 1e-5
+
+
+@pytest.mark.parametrize("task,O,A,B,K", [("pusht", 514, 2, 25, 6), ("robomimic_square", 555, 7, 5, 6), ("hook_package", 533, 21, 32, 1),
+                                           ("hook_package", 533, 21, 8, 40)])
+def test_generate_actions_other_tasks_and_long_solves(task, O, A, B, K):
+    """One launch for obs_encoder + time path + K steps + decoder at the other tasks' dims (decoder OUT = 16 * A: 32 and 112
+    columns leave most workgroups without an output_proj column; O = 514 / 555 end inside a 16-k piece), and K > 32, where the
+    time path runs as launches ahead of the kernel: against the per-launch path and the fp32 oracle."""
+    sd = O_make(O, A)
+    fw, dw = ops.FlowNetHandle(sd, DEV), ops.DecoderHandle(sd, DEV)
+    ow, ob = sd["obs_encoder.weight"].to(DEV), sd["obs_encoder.bias"].to(DEV)
+    obs = torch.randn(B, O, generator=torch.Generator().manual_seed(B + K)).to(DEV)
+    a, lat = ops.generate_actions(ow, ob, fw, dw, obs, K, return_latents=True)
+    ops.set_persistent_sampler(False)
+    b, latb = ops.generate_actions(ow, ob, fw, dw, obs, K, return_latents=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(a).all() and nerr(a, b) <= 3e-6 and nerr(lat, latb) <= 3e-6, (nerr(a, b), nerr(lat, latb))
+    ref = O_ref.generate_actions({k: v.double() for k, v in sd.items()}, obs.cpu().double(), K, 16, A)
+    assert nerr(a.reshape(B, -1), ref.reshape(B, -1)) <= 1e-5
+
+
+def O_make(O_, A):
+    return O_ref.make_state_dict(O_, A, seed=O_)
+
+
+O_ref = O
