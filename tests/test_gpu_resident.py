@@ -32,7 +32,7 @@ def net():
     return sd, ops.FlowNetHandle(sd, DEV)
 
 
-@pytest.mark.parametrize("B,K", [(25, 6), (1, 6), (5, 1), (16, 3), (17, 2), (32, 6), (32, 17)])
+@pytest.mark.parametrize("B,K", [(25, 6), (1, 6), (5, 1), (16, 3), (17, 2), (32, 6), (32, 17), (33, 2), (48, 6), (64, 6)])
 def test_resident_vs_per_launch_and_oracle(net, B, K):
     sd, fw = net
     lib = _lib.load()
@@ -103,7 +103,7 @@ def test_generate_actions_serving_batch(net):
 
 
 @pytest.mark.parametrize("task,O,A,B,K", [("pusht", 514, 2, 25, 6), ("robomimic_square", 555, 7, 5, 6), ("hook_package", 533, 21, 32, 1),
-                                           ("hook_package", 533, 21, 8, 40)])
+                                           ("hook_package", 533, 21, 8, 40), ("pusht", 514, 2, 64, 6), ("hook_package", 533, 21, 40, 3)])
 def test_generate_actions_other_tasks_and_long_solves(task, O, A, B, K):
     """One launch for obs_encoder + time path + K steps + decoder at the other tasks' dims (decoder OUT = 16 * A: 32 and 112
     columns leave most workgroups without an output_proj column; O = 514 / 555 end inside a 16-k piece), and K > 32, where the

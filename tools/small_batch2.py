@@ -21,7 +21,7 @@ def timed(fn, n=200):
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / n * 1e3
 
-for B in (1, 5, 25, 32):
+for B in (1, 5, 25, 32, 64):
     obs = torch.randn(B, 533).to(dev)
     x0 = torch.randn(B, 512).to(dev)
     out = torch.empty(B, 336, device=dev)

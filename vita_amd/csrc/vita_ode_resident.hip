@@ -1,5 +1,5 @@
-// TorchFlowMatcher.sample (flow_matchers.py:41-79) at SERVING batches (B <= 32 rows: eval_n_envs = 25 / 5,
-// default_policy.yaml:48) as ONE launch whose velocity-field weights stay resident in LDS across all K Euler steps.
+// TorchFlowMatcher.sample (flow_matchers.py:41-79) at SERVING batches (B <= 64 rows, in halves of 32: eval_n_envs = 25 / 5,
+// default_policy.yaml:48; the pusht batch of 64) as ONE launch whose velocity-field weights stay resident in LDS across all K Euler steps.
 //
 // At these batches a solve is ~60 dependent GEMMs of a few MFLOP each: the per-launch path is bound by kernel boundaries
 // and by re-reading 34 MB of weights per step (0.89 ms per 25-row solve).  Here:
@@ -39,7 +39,7 @@
 namespace vita {
 
 constexpr int RS_D = 512, RS_FF = 2048;          // D = H = 512, FF = 2048: the shapes whose slices fill LDS
-constexpr int RS_WG = 256, RS_NT = 512, RS_NW = RS_NT / 64, RS_ROWS = 32;
+constexpr int RS_WG = 256, RS_NT = 512, RS_NW = RS_NT / 64, RS_ROWS = 32, RS_MAXB = 64;
 constexpr int RS_KP1 = RS_D + 16, RS_KP2 = RS_FF + 16;   // LDS row strides: = 16 (mod 64) floats -> conflict-free ds_read_b128
 constexpr int RS_C2 = RS_D / RS_WG, RS_C8 = RS_FF / RS_WG;
 static_assert(RS_C2 == 2 && RS_C8 == 8, "slice widths");
@@ -151,6 +151,7 @@ __device__ __forceinline__ float kq_sum(float v) {
 struct PhaseIn {
     __amdgpu_buffer_rsrc_t ra;            // A operand (ASRC 0: blocked hand-off buffer; 1: the caller's row-major x0)
     unsigned lda_bytes;                   // ASRC 1: row stride
+    int row0;                             // first of the 32 rows this call multiplies (a multiple of 32: batches above 32 rows go in halves)
     int steps;                            // ASRC 2: A = the sinusoidal embedding of t_k = k / steps, row k < steps (pos_embed.py:11-18)
     const float* wl;                      // the weight slice in LDS, column c at wl + c * (KDIM + 16); GW: the (N, KDIM) matrix in global memory
     int gw_col0, gw_n;                    // GW: this workgroup's first column, and N (columns >= N read as zeros)
@@ -226,11 +227,11 @@ __device__ __forceinline__ bool rs_phase(const PhaseIn& in, float* red, float* s
 #pragma unroll
         for (int R = 0; R < 2; ++R) {
             if constexpr (ASRC == 1) {
-                const unsigned off = (unsigned)(16 * R + 4 * rq + i) * in.lda_bytes + (unsigned)kb * 4u;
+                const unsigned off = (unsigned)(in.row0 + 16 * R + 4 * rq + i) * in.lda_bytes + (unsigned)kb * 4u;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) a[R][s] = load16_sc1(in.ra, off + 64u * s);
             } else {      // block (row group 4 R + rq, k chunk kb / 4 + 4 s): 64 bytes, this lane's row at + 16 i
-                const unsigned off = ((unsigned)(4 * R + rq) * (unsigned)(KDIM / 4) + (unsigned)(kb >> 2)) * 64u + 16u * i;
+                const unsigned off = ((unsigned)((in.row0 >> 2) + 4 * R + rq) * (unsigned)(KDIM / 4) + (unsigned)(kb >> 2)) * 64u + 16u * i;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) a[R][s] = load16_sc1(in.ra, off + 256u * s);
             }
@@ -334,8 +335,8 @@ __device__ __forceinline__ bool rs_phase(const PhaseIn& in, float* red, float* s
 // The observation encoder's GEMM: A (nrows, Kact) and W (N, Kact) row-major with Kact not a multiple of 4 and rows that are not
 // 16-byte aligned (O = 533: 512 camera features + 21 joint positions), so both operands are read dword by dword.  Nothing of it is
 // written in this launch: plain loads, no wait.  Same lane layout and `red` result as rs_phase<1024, 1, ...>.
-__device__ __forceinline__ void rs_phase_unaligned(const float* __restrict__ A, int64_t lda, int nrows, int Kact, const float* __restrict__ W,
-                                                   int col0, int N, float* red) {
+__device__ __forceinline__ void rs_phase_unaligned(const float* __restrict__ A, int64_t lda, int row0, int nrows, int Kact,
+                                                   const float* __restrict__ W, int col0, int N, float* red) {
     constexpr int KDIM = 1024, NS = KDIM / 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int i = lane & 3, kq = (lane >> 2) & 3, rq = lane >> 4;
@@ -353,7 +354,7 @@ __device__ __forceinline__ void rs_phase_unaligned(const float* __restrict__ A, 
             wv[r] = (kin && col < N) ? W[(int64_t)col * Kact + k] : 0.f;
 #pragma unroll
             for (int R = 0; R < 2; ++R) {
-                const int row = 16 * R + 4 * rq + i;
+                const int row = row0 + 16 * R + 4 * rq + i;
                 a[R][r] = (kin && row < nrows) ? A[(int64_t)row * lda + k] : 0.f;
             }
         }
@@ -415,9 +416,12 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             copy_rows(q.w.fc1_w[l], 8 * c, 8, H, w_fc1 + (size_t)l * 8 * RS_KP1, RS_KP1);
         }
     }
-    // ---- this workgroup's two columns of the state: thread t < 32 keeps row t of x and of h in registers for the whole solve
-    const int row = tid;                          // meaningful for tid < 32
-    const bool mine = tid < RS_ROWS && row < B;
+    // ---- this workgroup's two columns of the state: thread t < B keeps row t of x and of h in registers for the whole solve.
+    // Batches above 32 rows go through every phase in halves of 32 rows (nh = 2): half hf is multiplied by one rs_phase call,
+    // its sums are turned into outputs by threads [32 hf, 32 hf + 32) (fc1: [64 hf, 64 hf + 64)), one wait and one publish per phase.
+    const int row = tid;                          // meaningful for tid < RS_MAXB
+    const bool mine = tid < RS_MAXB && row < B;
+    const int nh = (B + RS_ROWS - 1) / RS_ROWS;
     const int col2 = 2 * c;
     float x0v = 0.f, x1v = 0.f, h0v = 0.f, h1v = 0.f;
     {
@@ -453,11 +457,14 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
     if (q.obs_w != nullptr) {
         // ---- obs_encoder (vita_policy.py:194): the start of the flow; this workgroup's two columns of it are its x
         const float b0 = q.obs_b[col2], b1 = q.obs_b[col2 + 1];
-        rs_phase_unaligned(q.obs, q.ldobs, B, q.O, q.obs_w, col2, D, red);
-        if (tid < RS_ROWS) {
-            const f32x4 s = rs_sum4(red, row, 0);
-            x0v = s[0] + b0; x1v = s[1] + b1;
-            if (mine) store8_sc1(rxi, rs_blk(row, col2, D) * 4u, x0v, x1v);
+        for (int hf = 0; hf < nh; ++hf) {
+            rs_phase_unaligned(q.obs, q.ldobs, RS_ROWS * hf, B, q.O, q.obs_w, col2, D, red);
+            if ((tid >> 5) == hf) {
+                const f32x4 s = rs_sum4(red, row & 31, 0);
+                x0v = s[0] + b0; x1v = s[1] + b1;
+                if (mine) store8_sc1(rxi, rs_blk(row, col2, D) * 4u, x0v, x1v);
+            }
+            if (hf + 1 < nh) __syncthreads();
         }
         if (!q.tp) publish();        // otherwise the time path's first publish carries these stores too
         else __syncthreads();        // `red` is rewritten by the next phase
@@ -532,18 +539,23 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             const float b0 = q.w.in_b[col2], b1 = q.w.in_b[col2 + 1];
             PhaseIn in{};
             in.wl = w_in;
-            if (k == 0 && q.obs_w == nullptr) {       // the caller's row-major x0
-                in.ra = rs_rsrc(xs, (unsigned)(((int64_t)(B - 1) * lds_ + D) * 4));
-                in.lda_bytes = (unsigned)lds_ * 4u;
-                if (!rs_phase<RS_D, 1, 0, 1, false>(in, red, st, sy, stp)) return;
-            } else {
-                in.ra = rxi;
-                if (!rs_phase<RS_D, 1, 0, 0, false>(in, red, st, sy, stp)) return;
-            }
-            if (tid < RS_ROWS) {
-                const f32x4 s = rs_sum4(red, row, 0);
-                h0v = s[0] + b0; h1v = s[1] + b1;
-                if (mine) store8_sc1(rh, rs_blk(row, col2, H) * 4u, h0v, h1v);
+            for (int hf = 0; hf < nh; ++hf) {
+                in.row0 = RS_ROWS * hf;
+                if (k == 0 && q.obs_w == nullptr) {       // the caller's row-major x0
+                    in.ra = rs_rsrc(xs, (unsigned)(((int64_t)(B - 1) * lds_ + D) * 4));
+                    in.lda_bytes = (unsigned)lds_ * 4u;
+                    if (!rs_phase<RS_D, 1, 0, 1, false>(in, red, st, sy, stp)) return;
+                } else {
+                    in.ra = rxi;
+                    if (!rs_phase<RS_D, 1, 0, 0, false>(in, red, st, sy, stp)) return;
+                }
+                sy.target = 0;
+                if ((tid >> 5) == hf) {
+                    const f32x4 s = rs_sum4(red, row & 31, 0);
+                    h0v = s[0] + b0; h1v = s[1] + b1;
+                    if (mine) store8_sc1(rh, rs_blk(row, col2, H) * 4u, h0v, h1v);
+                }
+                if (hf + 1 < nh) __syncthreads();
             }
             publish();
         }
@@ -551,18 +563,23 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             const unsigned gamma_off = (unsigned)(((size_t)k * L + l) * 3 * H) * 4u;     // byte offset of (gamma | scale | shift) in the table
             // ---- fc1 + tanh-GELU on LN(h) * (1 + scale) + shift (:44-45, 19-24): 8 columns, thread (row, half) stores 4
             {
-                const int r8 = tid >> 1, c4 = (tid & 1) * 4;
+                const int r8 = tid >> 1, c4 = (tid & 1) * 4;      // thread (row r8, half of the 8 columns) for tid < 2 * RS_MAXB
                 f32x4 b = {0.f, 0.f, 0.f, 0.f};
-                if (tid < 2 * RS_ROWS) b = *reinterpret_cast<const f32x4*>(q.w.fc1_b[l] + 8 * c + c4);
+                if (tid < 2 * RS_MAXB) b = *reinterpret_cast<const f32x4*>(q.w.fc1_b[l] + 8 * c + c4);
                 PhaseIn in{};
                 in.ra = rh; in.wl = w_fc1 + (size_t)l * 8 * RS_KP1;
                 in.rln = rmod; in.ln_mul_off = gamma_off + H * 4u; in.ln_add_off = gamma_off + 2 * H * 4u;
-                if (!rs_phase<RS_D, 2, 1, 0, false>(in, red, st, sy, stp)) return;
-                if (tid < 2 * RS_ROWS) {
-                    f32x4 s = rs_sum4(red, r8, c4);
+                for (int hf = 0; hf < nh; ++hf) {
+                    in.row0 = RS_ROWS * hf;
+                    if (!rs_phase<RS_D, 2, 1, 0, false>(in, red, st, sy, stp)) return;
+                    sy.target = 0;
+                    if ((tid >> 6) == hf) {
+                        f32x4 s = rs_sum4(red, r8 & 31, c4);
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s[e] = act_gelu_tanh(s[e] + b[e]);
-                    if (r8 < B) store16_sc1(ru, rs_blk(r8, 8 * c + c4, FF) * 4u, s);
+                        for (int e = 0; e < 4; ++e) s[e] = act_gelu_tanh(s[e] + b[e]);
+                        if (r8 < B) store16_sc1(ru, rs_blk(r8, 8 * c + c4, FF) * 4u, s);
+                    }
+                    if (hf + 1 < nh) __syncthreads();
                 }
                 publish();
             }
@@ -572,12 +589,17 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
                 const float g0 = load4_sc1(rmod, gamma_off + (unsigned)col2 * 4u), g1 = load4_sc1(rmod, gamma_off + (unsigned)col2 * 4u + 4u);
                 PhaseIn in{};
                 in.ra = ru; in.wl = w_fc2 + (size_t)l * 2 * RS_KP2;
-                if (!rs_phase<RS_FF, 1, 0, 0, false>(in, red, st, sy, stp)) return;
-                if (tid < RS_ROWS) {
-                    const f32x4 s = rs_sum4(red, row, 0);
-                    const float v0 = (s[0] + b0) * g0, v1 = (s[1] + b1) * g1;
-                    h0v = h0v + v0; h1v = h1v + v1;
-                    if (mine) store8_sc1(rh, rs_blk(row, col2, H) * 4u, h0v, h1v);
+                for (int hf = 0; hf < nh; ++hf) {
+                    in.row0 = RS_ROWS * hf;
+                    if (!rs_phase<RS_FF, 1, 0, 0, false>(in, red, st, sy, stp)) return;
+                    sy.target = 0;
+                    if ((tid >> 5) == hf) {
+                        const f32x4 s = rs_sum4(red, row & 31, 0);
+                        const float v0 = (s[0] + b0) * g0, v1 = (s[1] + b1) * g1;
+                        h0v = h0v + v0; h1v = h1v + v1;
+                        if (mine) store8_sc1(rh, rs_blk(row, col2, H) * 4u, h0v, h1v);
+                    }
+                    if (hf + 1 < nh) __syncthreads();
                 }
                 publish();
             }
@@ -587,18 +609,23 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             const float b0 = q.w.out_b[col2], b1 = q.w.out_b[col2 + 1];
             PhaseIn in{};
             in.ra = rh; in.wl = w_out; in.ln_w = q.w.norm_w; in.ln_b = q.w.norm_b;
-            if (!rs_phase<RS_D, 1, 2, 0, false>(in, red, st, sy, stp)) return;
-            if (tid < RS_ROWS) {
-                const f32x4 s = rs_sum4(red, row, 0);
-                const float v0 = (s[0] + b0) * q.dt, v1 = (s[1] + b1) * q.dt;
-                x0v = x0v + v0; x1v = x1v + v1;
-                if (mine) {
-                    if (k + 1 < q.K || q.dec) store8_sc1(rxi, rs_blk(row, col2, D) * 4u, x0v, x1v);   // the next step's (or the decoder's) A operand
-                    if (q.traj || k + 1 == q.K) {                                                  // what the caller sees: row-major
-                        const __amdgpu_buffer_rsrc_t rxd = rs_rsrc(xd, (unsigned)(((int64_t)(B - 1) * ldd_ + D) * 4));
-                        store8_sc1(rxd, (unsigned)((int64_t)row * ldd_ + col2) * 4u, x0v, x1v);
+            for (int hf = 0; hf < nh; ++hf) {
+                in.row0 = RS_ROWS * hf;
+                if (!rs_phase<RS_D, 1, 2, 0, false>(in, red, st, sy, stp)) return;
+                sy.target = 0;
+                if ((tid >> 5) == hf) {
+                    const f32x4 s = rs_sum4(red, row & 31, 0);
+                    const float v0 = (s[0] + b0) * q.dt, v1 = (s[1] + b1) * q.dt;
+                    x0v = x0v + v0; x1v = x1v + v1;
+                    if (mine) {
+                        if (k + 1 < q.K || q.dec) store8_sc1(rxi, rs_blk(row, col2, D) * 4u, x0v, x1v);   // the next step's (or the decoder's) A operand
+                        if (q.traj || k + 1 == q.K) {                                                  // what the caller sees: row-major
+                            const __amdgpu_buffer_rsrc_t rxd = rs_rsrc(xd, (unsigned)(((int64_t)(B - 1) * ldd_ + D) * 4));
+                            store8_sc1(rxd, (unsigned)((int64_t)row * ldd_ + col2) * 4u, x0v, x1v);
+                        }
                     }
                 }
+                if (hf + 1 < nh) __syncthreads();
             }
             publish();
         }
@@ -613,10 +640,15 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             const float b0 = dw.in_b[col2], b1 = dw.in_b[col2 + 1];
             PhaseIn in{};
             in.ra = rxi; in.wl = dw.in_w; in.gw_col0 = col2; in.gw_n = 512;
-            if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
-            if (tid < RS_ROWS) {
-                const f32x4 s = rs_sum4(red, row, 0);
-                if (mine) store8_sc1(rda, rs_blk(row, col2, 512) * 4u, s[0] + b0, s[1] + b1);
+            for (int hf = 0; hf < nh; ++hf) {
+                in.row0 = RS_ROWS * hf;
+                if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
+                sy.target = 0;
+                if ((tid >> 5) == hf) {
+                    const f32x4 s = rs_sum4(red, row & 31, 0);
+                    if (mine) store8_sc1(rda, rs_blk(row, col2, 512) * 4u, s[0] + b0, s[1] + b1);
+                }
+                if (hf + 1 < nh) __syncthreads();
             }
             publish();
         }
@@ -625,10 +657,15 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
                 const float b0 = dw.fc1_b[l][col2], b1 = dw.fc1_b[l][col2 + 1];
                 PhaseIn in{};
                 in.ra = rda; in.wl = dw.fc1_w[l]; in.gw_col0 = col2; in.gw_n = 512;
-                if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
-                if (tid < RS_ROWS) {
-                    const f32x4 s = rs_sum4(red, row, 0);
-                    if (mine) store8_sc1(rdb, rs_blk(row, col2, 512) * 4u, act_gelu_erf(s[0] + b0), act_gelu_erf(s[1] + b1));
+                for (int hf = 0; hf < nh; ++hf) {
+                    in.row0 = RS_ROWS * hf;
+                    if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
+                    sy.target = 0;
+                    if ((tid >> 5) == hf) {
+                        const f32x4 s = rs_sum4(red, row & 31, 0);
+                        if (mine) store8_sc1(rdb, rs_blk(row, col2, 512) * 4u, act_gelu_erf(s[0] + b0), act_gelu_erf(s[1] + b1));
+                    }
+                    if (hf + 1 < nh) __syncthreads();
                 }
                 publish();
             }
@@ -636,10 +673,15 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
                 const float b0 = dw.fc2_b[l][col2], b1 = dw.fc2_b[l][col2 + 1];
                 PhaseIn in{};
                 in.ra = rdb; in.wl = dw.fc2_w[l]; in.gw_col0 = col2; in.gw_n = 512;
-                if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
-                if (tid < RS_ROWS) {
-                    const f32x4 s = rs_sum4(red, row, 0);
-                    if (mine) store8_sc1(rda, rs_blk(row, col2, 512) * 4u, s[0] + b0, s[1] + b1);
+                for (int hf = 0; hf < nh; ++hf) {
+                    in.row0 = RS_ROWS * hf;
+                    if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
+                    sy.target = 0;
+                    if ((tid >> 5) == hf) {
+                        const f32x4 s = rs_sum4(red, row & 31, 0);
+                        if (mine) store8_sc1(rda, rs_blk(row, col2, 512) * 4u, s[0] + b0, s[1] + b1);
+                    }
+                    if (hf + 1 < nh) __syncthreads();
                 }
                 publish();
             }
@@ -650,11 +692,16 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
             if (have) { b0 = dw.out_b[col2]; b1 = dw.out_b[col2 + 1]; }
             PhaseIn in{};
             in.ra = rda; in.wl = dw.out_w; in.gw_col0 = col2; in.gw_n = dw.OUT;
-            if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
-            if (tid < RS_ROWS && mine && have) {
-                const f32x4 s = rs_sum4(red, row, 0);
-                float* o = q.actions + (int64_t)row * q.lda + col2;       // nobody reads it in this launch: plain stores
-                o[0] = s[0] + b0; o[1] = s[1] + b1;
+            for (int hf = 0; hf < nh; ++hf) {
+                in.row0 = RS_ROWS * hf;
+                if (!rs_phase<RS_D, 1, 0, 0, true>(in, red, st, sy, stp)) return;
+                sy.target = 0;
+                if ((tid >> 5) == hf && mine && have) {
+                    const f32x4 s = rs_sum4(red, row & 31, 0);
+                    float* o = q.actions + (int64_t)row * q.lda + col2;       // nobody reads it in this launch: plain stores
+                    o[0] = s[0] + b0; o[1] = s[1] + b1;
+                }
+                if (hf + 1 < nh) __syncthreads();
             }
         }
     }
@@ -674,7 +721,7 @@ static int device_cus() {
 }
 
 bool ode_resident_dims(const vita_flownet_weights* w, int B) {
-    return w->D == RS_D && w->H == RS_D && w->FF == RS_FF && w->L >= 1 && w->L <= 4 && B >= 1 && B <= RS_ROWS;
+    return w->D == RS_D && w->H == RS_D && w->FF == RS_FF && w->L >= 1 && w->L <= 4 && B >= 1 && B <= RS_MAXB;
 }
 
 bool ode_resident_eligible(const vita_flownet_weights* w, int B, const float* x0, int64_t ldx0, const float* x_out, int64_t ldo) {
