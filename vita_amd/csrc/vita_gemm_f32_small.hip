@@ -10,7 +10,9 @@
 // wave order (deterministic) and 256 threads apply the epilogue on row-major float4s.  No LDS staging, no pipeline, and the
 // in-workgroup reduction replaces the split-K pass for K <= 1024 (above that a grid-level split feeds the usual
 // splitk_reduce_kernel).  A column operand (dgrad: B(n,k) = W[k][n]) is read with four coalesced dword loads per chunk.
-#include "vita_gemm_epilogue.h"
+#include <stdlib.h>
+
+#include "vita_gemm_dma_tile.h"
 
 namespace vita {
 
@@ -144,6 +146,172 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
     }
 }
 
+// The same tile with the operands staged through LDS (4 waves, k span <= 512).  In the kernel above adjacent lanes load
+// adjacent ROWS (the MFMA fragment layout), so every 4 lanes touch 4 cache lines and the loads run at a third of the rate
+// of a coalesced stream (measured in vita_ode_resident.hip: 28 against 70+ GB/s per CU); at M = 128 that is most of the
+// kernel.  Here every wave copies ITS k-slice of the two 32-row operand tiles into a private 32 KB LDS region with
+// global_load_lds (an instruction = 8 rows x 128 contiguous bytes; 16-byte chunks XOR-swizzled by (row >> 1) & 7 so that
+// the fragment reads are conflict-free), waits for its own DMAs block by block (no workgroup barrier: the region is the
+// wave's own) and reads the fragments back with ds_read_b128.  Same MFMAs in the same order on the same values as the
+// kernel above: the same bits.  A column operand (BCOL) keeps its four coalesced dword loads per chunk.
+template <bool BCOL>
+__global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) {
+    constexpr int NW = 4, KB = 32, NBLK = 4;                  // 32-k blocks per wave: kw <= 128
+    extern __shared__ __attribute__((aligned(16))) float stage[];     // [NW][A: NBLK x 32 x 32 | B: NBLK x 32 x 32]
+    __shared__ __attribute__((aligned(16))) float red[NW * 32 * SM_TS];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int fr = lane & 31, fh = lane >> 5;
+    const int ntile = p.tiles_n * ((p.M + 31) / 32);
+    const int split = p.sk_splits > 1 ? (int)blockIdx.x / ntile : 0;
+    const int bid = (int)blockIdx.x - split * ntile;
+    const int tile_m = bid / p.tiles_n, tile_n = bid - tile_m * p.tiles_n;
+    const int m0 = tile_m * 32, n0 = tile_n * 32;
+    const int kbase = split * p.sk_k;
+    const int Kend = p.sk_splits > 1 ? min(p.K, kbase + p.sk_k) : p.K;
+    const int k0 = kbase + wave * p.kw;
+    const int k1 = min(Kend, k0 + p.kw);
+    const int nch = k1 > k0 ? (k1 - k0 + 7) / 8 : 0;
+    float* sa = stage + wave * (2 * NBLK * 32 * KB);
+    float* sb = sa + NBLK * 32 * KB;
+
+    // epilogue operands of this thread's output float4, requested first (they return first: the DMA waits below count DMAs only)
+    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    const int row = m0 + lr, col = n0 + lc;
+    const EpiParams& e = p.epi;
+    const bool bwd = e.act_grad_z != nullptr;
+    const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
+    const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
+    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
+    const bool fast = e.partial == nullptr && e.vec && row < e.M && col + 3 < e.N;
+    f32x4 pbias = {0.f, 0.f, 0.f, 0.f}, pzin = pbias, prs = pbias, pg = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
+    if (fast) {
+        if (e.bias) pbias = *reinterpret_cast<const f32x4*>(e.bias + col);
+        if (bwd) pzin = *reinterpret_cast<const f32x4*>(e.act_grad_z + (int64_t)row * e.ld_act_grad_z + col);
+        if (gate_vec) pg = *reinterpret_cast<const f32x4*>(e.gate + col);
+        else if (gate_mat) pg = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
+        if (e.resid) prs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+    }
+
+    // ---- DMA sources: lane l of the instruction for rows 8 j .. 8 j + 7 writes row 8 j + l / 8, chunk position l % 8,
+    //      so it fetches chunk (l % 8) ^ swz(row) of that row's 128-byte piece
+    const int dr = lane >> 3, dslot = lane & 7;
+    const float* asrc[4];
+    const float* bsrc[4];
+    int dchunk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 8 * j + dr;
+        dchunk[j] = (dslot ^ swz<KB>(r)) * 4;
+        asrc[j] = p.X + (int64_t)min(m0 + r, p.M - 1) * p.ldx;
+        bsrc[j] = BCOL ? nullptr : p.W + (int64_t)min(n0 + r, p.N - 1) * p.ldw;
+    }
+#pragma unroll
+    for (int kb = 0; kb < NBLK; ++kb) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int k = k0 + KB * kb + dchunk[j];
+            const bool ok = k < k1;                           // K % 4 == 0 and k % 4 == 0: the four k exist together
+            dma16(ok ? asrc[j] + k : g_zero_chunk, sa + (kb * 32 + 8 * j) * KB);
+            if constexpr (!BCOL) dma16(ok ? bsrc[j] + k : g_zero_chunk, sb + (kb * 32 + 8 * j) * KB);
+        }
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int fsw = swz<KB>(fr);
+    if constexpr (BCOL) {
+        // column operand: registers, as in the kernel above (coalesced across lanes); then everything has landed at once
+        const int ncol = min(n0 + fr, p.N - 1);
+        const float* brow = p.W + ncol;
+        f32x4 b[4 * NBLK];
+#pragma unroll
+        for (int c = 0; c < 4 * NBLK; ++c) {
+            const int kk = k0 + c * 8 + fh * 4;
+            b[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (c < nch && kk < k1) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) b[c][e4] = brow[(int64_t)(kk + e4) * p.ldw];
+            }
+        }
+        wait_vmcnt<0>();
+#pragma unroll
+        for (int c = 0; c < 4 * NBLK; ++c) {
+            if (c < nch) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(sa + ((c >> 2) * 32 + fr) * KB + ((((c & 3) * 2 + fh) ^ fsw) * 4));
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e4], b[c][e4], acc, 0, 0, 0);
+            }
+        }
+    } else {
+        auto block = [&](int kb) {
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = kb * 4 + cc;
+                if (c < nch) {
+                    const int off = (kb * 32 + fr) * KB + (((cc * 2 + fh) ^ fsw) * 4);
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(sa + off);
+                    const f32x4 b = *reinterpret_cast<const f32x4*>(sb + off);
+#pragma unroll
+                    for (int e4 = 0; e4 < 4; ++e4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[e4], b[e4], acc, 0, 0, 0);
+                }
+            }
+        };
+        // the wave's DMAs complete in order: block kb is there once at most 8 * (3 - kb) of them are still out
+        wait_vmcnt<24>(); block(0);
+        wait_vmcnt<16>(); block(1);
+        wait_vmcnt<8>();  block(2);
+        wait_vmcnt<0>();  block(3);
+    }
+
+    float* mine = red + wave * (32 * SM_TS);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * SM_TS + fr] = acc[r];
+    __syncthreads();
+    f32x4 s = *reinterpret_cast<const f32x4*>(red + lr * SM_TS + lc);
+#pragma unroll
+    for (int w = 1; w < NW; ++w) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * (32 * SM_TS) + lr * SM_TS + lc);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s[k] += t[k];
+    }
+    if (row >= e.M || col >= e.N) return;
+    if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
+        float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
+        if (col + 3 < e.N) *reinterpret_cast<f32x4*>(dst) = s;
+        else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
+        return;
+    }
+    if (fast) {
+        const f32x4 bias = pbias, zin = pzin, g = pg, rs = prs;
+        f32x4 pre, out;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float z = s[k] + bias[k];
+            pre[k] = z;
+            float v = bwd ? z * act_grad(zin[k], e.act) : apply_act(z, e.act);
+            if (has_gate) v = v * g[k];
+            if (e.resid) v = rs[k] + v;
+            out[k] = v;
+        }
+        if (e.preact) *reinterpret_cast<f32x4*>(e.preact + (int64_t)row * e.ld_preact + col) = pre;
+        *reinterpret_cast<f32x4*>(e.Y + (int64_t)row * e.ldy + col) = out;
+    } else {
+        for (int k = 0; k < 4 && col + k < e.N; ++k) {
+            const int cc = col + k;
+            const float z = s[k] + (e.bias ? e.bias[cc] : 0.f);
+            if (e.preact) e.preact[(int64_t)row * e.ld_preact + cc] = z;
+            float v = bwd ? z * act_grad(e.act_grad_z[(int64_t)row * e.ld_act_grad_z + cc], e.act) : apply_act(z, e.act);
+            const float g = gate_vec ? e.gate[cc] : (gate_mat ? e.gate[(int64_t)row * e.ld_gate + cc] : e.gate_scalar);
+            if (has_gate) v = v * g;
+            if (e.resid) v = e.resid[(int64_t)row * e.ld_resid + cc] + v;
+            e.Y[(int64_t)row * e.ldy + cc] = v;
+        }
+    }
+}
+
 // Shapes this kernel is meant for.  k_split = 0: the caller has no split-K scratch.
 bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws) {
 #ifdef VITA_NO_SMALL_GEMM
@@ -179,6 +347,14 @@ int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* 
     const int nw = kspan <= 512 ? 4 : 8;
     p.kw = ((kspan + nw - 1) / nw + 7) & ~7;
     const unsigned grid = (unsigned)(p.tiles_n * ((a.M + 31) / 32) * (p.sk_splits > 1 ? p.sk_splits : 1));
+    static const bool no_lds = getenv("VITA_SMALL_NO_LDS") != nullptr && atoi(getenv("VITA_SMALL_NO_LDS")) != 0;
+    if (nw == 4 && p.kw <= 128 && !no_lds) {      // operands through LDS (coalesced DMA): the same bits, faster loads
+        constexpr size_t lds = (size_t)4 * 2 * 4 * 32 * 32 * sizeof(float);
+        if (a.b_col) hipLaunchKernelGGL((gemm_f32_small_lds_kernel<true>), dim3(grid), dim3(256), lds, stream, p);
+        else hipLaunchKernelGGL((gemm_f32_small_lds_kernel<false>), dim3(grid), dim3(256), lds, stream, p);
+        VITA_CHECK_HIP(hipGetLastError());
+        return VITA_OK;
+    }
     if (a.b_col) {
         if (nw == 4) hipLaunchKernelGGL((gemm_f32_small_kernel<true, 4>), dim3(grid), dim3(256), 0, stream, p);
         else hipLaunchKernelGGL((gemm_f32_small_kernel<true, 8>), dim3(grid), dim3(512), 0, stream, p);
