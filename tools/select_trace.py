@@ -1,0 +1,18 @@
+"""select_action at 25 envs, 20 re-solves, for rocprofv3 --kernel-trace (what is launched around the resident kernel)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vita_amd.config import default_config
+from vita_amd.policy import VitaPolicy
+dev = torch.device("cuda:0")
+cfg = default_config("hook_package")
+S, A = cfg.task.state_dim, cfg.task.action_dim
+stats = {cfg.task.state_key: {"mean": [0.1] * S, "std": [0.9] * S}, cfg.task.action_key: {"mean": [0.0] * A, "std": [1.2] * A}}
+torch.manual_seed(0)
+pol = VitaPolicy(cfg, stats).to(dev)
+ncam = len(cfg.task.image_keys)
+batch = {cfg.task.state_key: torch.randn(25, S, device=dev), "observation.features": torch.relu(torch.randn(25, 512 * ncam, device=dev))}
+for _ in range(20):
+    pol.reset()
+    a = pol.select_action(batch)
+    a.cpu()

@@ -28,6 +28,7 @@ int set_ode_persistent(int on);   // returns the previous setting
 void set_ode_persistent_stamps(void* device_buf);
 void* ode_persistent_stamps();
 size_t ode_persistent_status_offset();
+int device_cus();                  // compute units of the current device (cached per device; <= 0: unknown)
 bool ode_persistent_enabled();     // the process-wide switch (VITA_NO_PERSISTENT / vita_ode_sample_set_persistent)
 // the weights-resident Euler sampler for serving batches (vita_ode_resident.hip): one launch, weights in LDS for all K steps
 bool ode_resident_dims(const vita_flownet_weights* w, int B);

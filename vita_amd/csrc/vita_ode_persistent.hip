@@ -289,7 +289,9 @@ bool ode_persistent_eligible(const vita_flownet_weights* w, int B, const float* 
     if ((B / 256) % rg_per_launch) return false;
     if (!al(x0) || !al(x_out) || ldx0 % 4 || ldo % 4) return false;
     if ((size_t)B * (size_t)(w->FF > ldo ? w->FF : ldo) * 4 >= (size_t(1) << 31)) return false;   // 32-bit store offsets
-    return true;
+    // every workgroup of a launch must be resident at once (a team waits for its members): one per CU, 256 per launch.  A device
+    // that shows fewer CUs (a compute partition, a CU mask) keeps the per-launch path
+    return device_cus() >= 256;
 }
 
 // Enqueues the phase-table build, the memset of the hand-off state and the persistent launch(es).

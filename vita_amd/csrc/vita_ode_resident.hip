@@ -709,7 +709,7 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
 
 // ---- host side -------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_cus[64];
-static int device_cus() {
+int device_cus() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     int n = g_cus[dev].load(std::memory_order_relaxed);
