@@ -321,7 +321,13 @@ int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float*
 /* ---------------------------------------------------------------------------------------
  * Training forward + backward of the whole hot path in one call.
  * --------------------------------------------------------------------------------------- */
-enum { VITA_ENC_CNN = 0, VITA_ENC_SIMPLE = 1 };
+enum { VITA_ENC_CNN = 0, VITA_ENC_SIMPLE = 1,
+       /* the caller's own action encoder (any module: the reference's TransformerActionEncoder, action_ae.py:36-108, a VAE variant ...):
+        * vita_compute_loss_f32 only.  In the weights descriptor set A, T, D and proj_w = the encoder's output, contiguous (B, D) rows;
+        * in the gradient descriptor proj_w = the (B, D) buffer that receives d loss / d latents (zeros under freeze_encoder), from
+        * which the caller's autograd continues into its module.  Every other field is ignored; variational must be 0 (a variational
+        * module samples, and adds its KL term, on the caller's side). */
+       VITA_ENC_EXTERNAL = 2 };
 
 typedef struct vita_encoder_weights {
     int32_t kind; /* VITA_ENC_CNN: CNNActionEncoder (action_ae.py:282-327); VITA_ENC_SIMPLE: SimpleActionEncoder (:111-170) */

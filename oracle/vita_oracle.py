@@ -568,8 +568,10 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
                  decode_flow_latents: bool = True, sigma: float = 0.0,
                  freeze_encoder: bool = False, freeze_decoder: bool = False,
                  kl_weight: float = 0.0, enc_noise: Tensor | None = None,
-                 fm_kind: str = "conditional", fm_noise: Tensor | None = None):
+                 fm_kind: str = "conditional", fm_noise: Tensor | None = None, enc_latents: Tensor | None = None):
     """VitaPolicy.compute_loss, vita_policy.py:112-189, from observer features on, with the
+    (enc_latents: the action latents of an encoder that is not in `sd` — another encoder_type's module — instead of
+    action_encode(sd, ...); everything downstream is unchanged)
     freeze flags of :119,142-143,153,174,183.  A state dict whose action_encoder.latent_proj is
     2*latent_dim wide is the variational autoencoder (use_variational, :120-121,146-150):
     `enc_noise` is the posterior's randn_like draw (None = eval mode's deterministic posterior).
@@ -580,8 +582,10 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
     B = obs_features.shape[0]
     m = {}
     obs_latents = obs_encode(sd, obs_features)                                  # :114
-    vae = is_variational(sd)
-    if vae:                                                                     # :121
+    vae = enc_latents is None and is_variational(sd)
+    if enc_latents is not None:
+        action_latents = enc_latents
+    elif vae:                                                                   # :121
         post_mean, post_logvar, action_latents = vae_cnn_action_encode(sd, gt_actions, enc_noise)
     else:
         action_latents = action_encode(sd, gt_actions)                          # :123

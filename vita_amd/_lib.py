@@ -139,7 +139,7 @@ class Bf16Weights(C.Structure):
     ]
 
 
-ENC_CNN, ENC_SIMPLE = 0, 1
+ENC_CNN, ENC_SIMPLE, ENC_EXTERNAL = 0, 1, 2
 FM_CONDITIONAL, FM_TARGET, FM_SCHRODINGER = 0, 1, 2
 LOSS_NAMES = ("loss", "flow_loss", "consistency_loss", "flow_action_recon_loss", "enc_action_recon_loss", "enc_contrastive_loss",
               "flow_contrastive_loss", "action_kl_loss")

@@ -599,12 +599,17 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     s.flow = carve_flow_train(c, w.flow, B, K, train);
     s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
-    else s.cnn = carve_cnn(c, w.enc, B, train);
+    else if (w.enc.kind == VITA_ENC_CNN) s.cnn = carve_cnn(c, w.enc, B, train);
     s.bytes = c.off;
     return s;
 }
 
 int check_enc_weights(const vita_encoder_weights* w, const char* who) {
+    if (w->kind == VITA_ENC_EXTERNAL) {      // the caller's own action encoder: proj_w = its output (B, D), nothing else is read
+        VITA_REQUIRE(w->A > 0 && w->T > 0 && w->D > 0 && w->proj_w != nullptr && w->variational == 0,
+                     "%s: an external encoder needs A, T, D, its latents in proj_w, and variational = 0", who);
+        return VITA_OK;
+    }
     VITA_REQUIRE(w->kind == VITA_ENC_CNN || w->kind == VITA_ENC_SIMPLE, "%s: unknown encoder kind %d", who, w->kind);
     VITA_REQUIRE(w->A > 0 && w->T > 0 && w->C > 0 && w->D > 0 && w->NL >= 0 && w->NL <= VITA_MAX_LAYERS, "%s: bad encoder dims", who);
     VITA_REQUIRE(w->proj_w && w->proj_b, "%s: null encoder projection", who);
@@ -639,6 +644,7 @@ int zero_encoder_grads(const vita_encoder_weights& g, hipStream_t st) {
         VITA_CHECK_HIP(hipMemsetAsync(mut(p), 0, n * sizeof(float), st));
         return VITA_OK;
     };
+    if (g.kind == VITA_ENC_EXTERNAL) return VITA_OK;     // d loss / d latents is zeroed by the caller of this (it knows B)
     if (g.kind == VITA_ENC_SIMPLE) {
         VITA_TRY(z(g.proj_w, (size_t)g.C * g.A)); VITA_TRY(z(g.proj_b, (size_t)g.C));
         for (int i = 0; i < g.NL; ++i) {
@@ -655,6 +661,10 @@ int zero_encoder_grads(const vita_encoder_weights& g, hipStream_t st) {
 }
 
 int encoder_fwd(const vita_encoder_weights& w, const StepWs& s, const float* actions, float* z1, int64_t ldz, int B, hipStream_t st) {
+    if (w.kind == VITA_ENC_EXTERNAL) {       // the latents were computed by the caller's module (contiguous (B, D) rows)
+        VITA_CHECK_HIP(hipMemcpy2DAsync(z1, (size_t)ldz * 4, w.proj_w, (size_t)w.D * 4, (size_t)w.D * 4, (size_t)B, hipMemcpyDeviceToDevice, st));
+        return VITA_OK;
+    }
     if (w.kind == VITA_ENC_SIMPLE) {
         VITA_REQUIRE(ldz == w.D, "simple encoder output must be contiguous");
         return stack_fwd(stack_of_simple_encoder(w), s.senc, actions, w.A, B * w.T, z1, st);
@@ -882,7 +892,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     if (nce_enc || nce_flow) VITA_TRY(launch_axpy(s.dz0c, s.dz0, (int64_t)B * D, st));
     // encoders (on their own stream when forking)
     auto encoders_bwd = [&](float* cs, hipStream_t es) -> int {
-        if (fe) {   // :119 the action latents were computed without grad
+        if (w->enc.kind == VITA_ENC_EXTERNAL) {   // hand d loss / d latents back: the caller's autograd continues into its module
+            if (fe) VITA_CHECK_HIP(hipMemsetAsync(mut(g.enc.proj_w), 0, (size_t)B * D * 4, es));
+            else VITA_CHECK_HIP(hipMemcpyAsync(mut(g.enc.proj_w), dz1, (size_t)B * D * 4, hipMemcpyDeviceToDevice, es));
+        } else if (fe) {   // :119 the action latents were computed without grad
             VITA_TRY(zero_encoder_grads(g.enc, es));
         } else if (w->enc.kind == VITA_ENC_SIMPLE) {
             VITA_TRY(stack_bwd(stack_of_simple_encoder(w->enc), stack_of_simple_encoder(g.enc), s.senc, actions, w->enc.A, B * w->enc.T, z1, dz1,
@@ -1338,6 +1351,7 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     VITA_TRY(check_mfw(&w->flow, who));
     VITA_TRY(check_dec_weights(&w->dec, who));
     VITA_TRY(check_enc_weights(&w->enc, who));
+    VITA_REQUIRE(w->enc.kind != VITA_ENC_EXTERNAL, "%s: an external action encoder is built for vita_compute_loss_f32 only", who);
     VITA_REQUIRE(!w->enc.variational || w->enc.kind == VITA_ENC_CNN, "%s: the variational encoder is the CNN one", who);
     VITA_REQUIRE(cfg->kl_weight >= 0.f, "%s: kl_weight must be >= 0", who);
     VITA_REQUIRE(w->flow.D == w->dec.D && w->flow.D == w->enc.D && w->dec.OUT == w->enc.T * w->enc.A, "%s: latent / action dims differ", who);

@@ -846,7 +846,10 @@ class PolicyHandle:
     tensors are used in place (they must be contiguous fp32 on the GPU): that is what a gradient descriptor needs,
     since the kernels write into them."""
 
-    def __init__(self, sd: Mapping[str, Tensor], device, pred_horizon: int = 16, strict: bool = False):
+    def __init__(self, sd: Mapping[str, Tensor], device, pred_horizon: int = 16, strict: bool = False,
+                 external_encoder_action_dim: Optional[int] = None):
+        """external_encoder_action_dim: the action encoder is the caller's own module (VITA_ENC_EXTERNAL): `sd` holds no
+        action_encoder.* tensors, compute_loss takes the encoder's output as `enc_latents`."""
         device = torch.device(device)
         self.device = device
         self.t = {}
@@ -857,7 +860,10 @@ class PolicyHandle:
         w.obs_w, w.obs_b = ow.data_ptr(), g("obs_encoder.bias").data_ptr()
         _fill_flow(w.flow, g, "flow_net.", sd)
         _fill_dec(w.dec, g, "action_decoder.", sd)
-        _fill_enc(w.enc, g, "action_encoder.", sd, pred_horizon, ow.shape[0])
+        if external_encoder_action_dim is not None:
+            w.enc.kind, w.enc.A, w.enc.T, w.enc.D = L.ENC_EXTERNAL, int(external_encoder_action_dim), pred_horizon, ow.shape[0]
+        else:
+            _fill_enc(w.enc, g, "action_encoder.", sd, pred_horizon, ow.shape[0])
         self.w = w
         self.O, self.D, self.T, self.A, self.OUT = w.O, w.flow.D, w.enc.T, w.enc.A, w.dec.OUT
 
@@ -896,9 +902,11 @@ def _event_handles(events, who: str):
 
 def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, *, grads: Optional[PolicyHandle] = None,
                  pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None,
-                 enc_noise: Optional[Tensor] = None, fm_noise: Optional[Tensor] = None):
+                 enc_noise: Optional[Tensor] = None, fm_noise: Optional[Tensor] = None, enc_latents: Optional[Tensor] = None):
     """VitaPolicy.compute_loss (+ backward when `grads` is given), vita_policy.py:112-189.  Returns
-    (losses (8,) device tensor indexed as _lib.LOSS_NAMES, d_obs_features or None).  No host sync."""
+    (losses (8,) device tensor indexed as _lib.LOSS_NAMES, d_obs_features or None).  No host sync.
+    enc_latents: with an external action encoder (PolicyHandle(external_encoder_action_dim=...)) the (B, D) output of the
+    caller's module; the return value then has a third entry, d loss / d enc_latents (None without `grads`)."""
     lib = L.load()
     obs_features = _rows(obs_features, "compute_loss: obs_features")
     actions = _f32(actions, "compute_loss: actions").contiguous()
@@ -930,9 +938,24 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
             raise L.VitaHipError(f"compute_loss: {len(ev)} grad_ready events; pass 3, or 3 + L = {3 + pw.w.flow.L}")
         cfg = L.LossConfig.from_buffer_copy(cfg)
         cfg.grad_ready_layers = 1
-    nbytes = lib.vita_compute_loss_workspace_bytes(C.byref(pw.w), C.byref(cfg), B)
+    external = pw.w.enc.kind == L.ENC_EXTERNAL
+    dlat = None
+    wdesc, gdesc = pw.w, (grads.w if grads is not None else None)
+    if external != (enc_latents is not None):
+        raise L.VitaHipError("compute_loss: enc_latents goes with an external action encoder, and only with one")
+    if external:
+        enc_latents = _f32(enc_latents, "compute_loss: enc_latents").contiguous()
+        if tuple(enc_latents.shape) != (B, pw.D):
+            raise L.VitaHipError(f"compute_loss: enc_latents {tuple(enc_latents.shape)} must be (B, D) = ({B}, {pw.D})")
+        wdesc = L.PolicyWeights.from_buffer_copy(pw.w)
+        wdesc.enc.proj_w = enc_latents.data_ptr()
+        if grads is not None:
+            dlat = torch.empty((B, pw.D), dtype=torch.float32, device=dev)
+            gdesc = L.PolicyWeights.from_buffer_copy(grads.w)
+            gdesc.enc.proj_w = dlat.data_ptr()
+    nbytes = lib.vita_compute_loss_workspace_bytes(C.byref(wdesc), C.byref(cfg), B)
     ws = workspace(dev, nbytes)
-    L.check(lib.vita_compute_loss_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
+    L.check(lib.vita_compute_loss_f32(C.byref(wdesc), C.byref(gdesc) if gdesc is not None else None, C.byref(cfg),
                                       obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(),
                                       pair_i.data_ptr() if pair_i is not None else None,
                                       pair_j.data_ptr() if pair_j is not None else None,
@@ -940,6 +963,8 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
                                       enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
                                       dobs.data_ptr() if dobs is not None else None, pw.O, ev, ws.data_ptr(), ws.numel(),
                                       _stream(obs_features)), "vita_compute_loss_f32")
+    if external:
+        return losses, dobs, dlat
     return losses, dobs
 
 

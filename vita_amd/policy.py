@@ -204,13 +204,20 @@ class _FusedLoss(torch.autograd.Function):
     fused forward+backward; backward hands the staged gradients to autograd (scaled by the incoming grad)."""
 
     @staticmethod
-    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, *params):
+    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, enc_latents, *params):
         pw, gw, gsd = policy._train_handles(stage=True)
         frozen = policy.frozen_prefixes()
         staged = [None if k.startswith(frozen) else gsd[k] for k, _ in policy.hot_path_named_parameters()]
         need_dobs = obs_features.requires_grad
-        losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
-                                        need_dobs=need_dobs, enc_noise=enc_noise, fm_noise=fm_noise)
+        ctx.dlat = None
+        if enc_latents is not None:     # an external action encoder: its output goes in, d loss / d output comes back
+            losses, dobs, dlat = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i,
+                                                  pair_j=pair_j, need_dobs=need_dobs, enc_noise=enc_noise, fm_noise=fm_noise,
+                                                  enc_latents=enc_latents.detach())
+            ctx.dlat = dlat if enc_latents.requires_grad else None
+        else:
+            losses, dobs = ops.compute_loss(pw, policy._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
+                                            need_dobs=need_dobs, enc_noise=enc_noise, fm_noise=fm_noise)
         ctx.staged, ctx.dobs, ctx.buf = staged, dobs, policy._cache["stage_buf"]
         ctx.mark_non_differentiable(losses)
         return losses[0].clone(), losses
@@ -219,7 +226,8 @@ class _FusedLoss(torch.autograd.Function):
     def backward(ctx, gout, _):
         ctx.buf.mul_(gout)      # ONE pass over the flat staging buffer (the incoming grad is a device scalar: no host check)
         dobs = ctx.dobs * gout if ctx.dobs is not None else None
-        return (None, dobs, None, None, None, None, None, None) + tuple(ctx.staged)
+        dlat = ctx.dlat * gout if ctx.dlat is not None else None
+        return (None, dobs, None, None, None, None, None, None, dlat) + tuple(ctx.staged)
 
 
 class _FusedMeanFlowLoss(torch.autograd.Function):
@@ -253,7 +261,11 @@ class VitaPolicy(nn.Module):
     # flat-buffer segment order = the order gradients become final in the backward pass (vita_loss_step.hip)
     BUCKET_PREFIXES = (("action_decoder.",), ("flow_net.",), ("action_encoder.", "obs_encoder."))
 
-    def __init__(self, config, stats, observer: Optional[nn.Module] = None):
+    def __init__(self, config, stats, observer: Optional[nn.Module] = None, action_encoder: Optional[nn.Module] = None):
+        """action_encoder: an nn.Module mapping normalised actions (B, T, A) to latents (B, latent_dim) that replaces the
+        configured one (for instance the reference's own module of a non-default encoder type).  It runs under torch autograd
+        and meets the fused path at the latents (VITA_ENC_EXTERNAL, vita_amd/encoders.py); `encoder_type: transformer` builds
+        vita_amd.encoders.TransformerActionEncoder this way."""
         super().__init__()
         self.config = config
         self.stats = stats
@@ -289,8 +301,21 @@ class VitaPolicy(nn.Module):
             raise NotImplementedError("action_ae.use_variational with decoder_type 'cnn' (CNNActionDecoder, action_vae.py:232-298) "
                                       "is outside this build's fused training path; decoder_type 'simple' is built")
         self.obs_encoder = nn.Linear(self.obs_dim, self.latent_dim)                                      # :77
-        self.action_encoder = make_action_encoder(net.encoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
-                                                  net.enc_hidden_dim, net.num_layers, bool(self.use_action_vae))   # :101-110
+        self.external_encoder = action_encoder is not None or (net.encoder_type == "transformer" and not self.use_action_vae)
+        if action_encoder is not None:
+            self.action_encoder = action_encoder
+        elif self.external_encoder:                                                                      # action_ae.py:354-364
+            from .encoders import TransformerActionEncoder
+            self.action_encoder = TransformerActionEncoder(enc_hidden_dim=net.enc_hidden_dim, latent_dim=self.latent_dim,
+                                                           num_heads=net.num_heads, pred_horizon=self.pred_horizon,
+                                                           action_dim=self.action_dim, num_layers=net.num_layers,
+                                                           mlp_ratio=net.get("mlp_ratio", 4.0), dropout=net.get("dropout", 0.0))
+        else:
+            self.action_encoder = make_action_encoder(net.encoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
+                                                      net.enc_hidden_dim, net.num_layers, bool(self.use_action_vae))   # :101-110
+        if self.external_encoder and self.use_action_vae:
+            raise NotImplementedError("an external action encoder with action_ae.use_variational is not built (the module would "
+                                      "have to sample and add its own KL term)")
         self.action_decoder = make_action_decoder(net.decoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
                                                   net.dec_hidden_dim, net.num_layers)
         fn = pol.flow_net
@@ -304,6 +329,8 @@ class VitaPolicy(nn.Module):
         self._mf_cfg = None
         if self.mean_flow != isinstance(self.FM, MeanFlowMatcher):
             raise ValueError("flow_net 'simple_mean_flow_net' goes with the 'mean' / 'improved_mean' flow matchers, and only with them")
+        if self.mean_flow and self.external_encoder:
+            raise NotImplementedError("an external / transformer action encoder is built for the default (torchcfm) matchers' fused step only")
         if self.mean_flow:
             self.flow_net = make_mean_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)
         else:
@@ -360,6 +387,8 @@ class VitaPolicy(nn.Module):
         out = []
         for prefixes in self.BUCKET_PREFIXES:
             for k, p in named.items():
+                if self.external_encoder and k.startswith("action_encoder."):
+                    continue        # a torch module beside the fused path: its gradients come through autograd
                 if k.startswith(prefixes) and p.requires_grad:
                     out.append((k, p))
         return out
@@ -457,7 +486,8 @@ class VitaPolicy(nn.Module):
             if self.mean_flow:
                 c = (self._key(), ops.MeanFlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), None)
             else:
-                c = (self._key(), ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), ops.PolicyHandle(sd, dev, self.pred_horizon))
+                c = (self._key(), ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev),
+                     ops.PolicyHandle(sd, dev, self.pred_horizon, external_encoder_action_dim=self.action_dim if self.external_encoder else None))
             self._cache["infer"] = c
         return c[1], c[2], c[3]
 
@@ -484,7 +514,8 @@ class VitaPolicy(nn.Module):
                 gsd = {k: torch.zeros_like(p.data) for k, p in named}
             dev = self.obs_encoder.weight.device
             handle = ops.MeanFlowPolicyHandle if self.mean_flow else ops.PolicyHandle
-            c = (self._key(), handle(sd, dev, self.pred_horizon, strict=True), handle(gsd, dev, self.pred_horizon, strict=True), gsd)
+            kw = {"external_encoder_action_dim": self.action_dim} if self.external_encoder else {}
+            c = (self._key(), handle(sd, dev, self.pred_horizon, strict=True, **kw), handle(gsd, dev, self.pred_horizon, strict=True, **kw), gsd)
             self._cache[slot] = c
         return c[1], c[2], c[3]
 
@@ -505,7 +536,8 @@ class VitaPolicy(nn.Module):
         return self.compute_loss(batch)
 
     # -- the hot path -----------------------------------------------------------------------------------
-    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None, enc_noise=None, fm_noise=None):
+    def _draw(self, batch_size, dev, t=None, pair_i=None, pair_j=None, obs_features=None, actions=None, enc_noise=None, fm_noise=None,
+              enc_latents=None):
         """The host-side random draws of one compute_loss call, in the reference's order: the variational posterior's
         eps (torch.randn_like on the device, dists.py:20; training mode only, vita_policy.py:121), then t ~ U(0,1) and the
         OT pairing (flow_matchers.py:34 -> torchcfm), then the matcher's eps = randn_like(x0) when its xt uses it (sigma > 0,
@@ -520,7 +552,7 @@ class VitaPolicy(nn.Module):
             # the plan needs the latents: one encoder pass (forward only) — the reference pays the same sync
             _, _, pw = self._infer_handles()
             z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
-            z1 = ops.action_encoder_forward(pw, actions)
+            z1 = enc_latents.detach() if enc_latents is not None else ops.action_encoder_forward(pw, actions)
             if self.use_action_vae:     # (B, 2D) rows [mean | logvar]; the sample feeds only the host-side OT plan here
                 mean, logvar = z1[:, :self.latent_dim], z1[:, self.latent_dim:]
                 z1 = mean if enc_noise is None else mean + torch.exp(0.5 * logvar) * enc_noise
@@ -539,6 +571,9 @@ class VitaPolicy(nn.Module):
         if self.inference_only:
             raise NotImplementedError(f"training with flow matcher '{self.config.policy.flow_matcher.name}' is not built "
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
+        if self.external_encoder:
+            raise NotImplementedError("the native trainer (flat buffers, fused optimizer) has no external / transformer action encoder: "
+                                      "train it through compute_loss(...).backward() with a torch optimizer (the drop-in path)")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
         pw, gw, gsd = self._train_handles()
@@ -573,15 +608,19 @@ class VitaPolicy(nn.Module):
         actions = batch[self.config.task.action_key]
         if self.mean_flow:
             return self._compute_loss_meanflow(obs_features, actions, t, pair_i, enc_noise)
+        enc_latents = None
+        if self.external_encoder:       # :118-123 — under no_grad when the encoder is frozen
+            with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_action_encoder):
+                enc_latents = self.action_encoder(actions)
         t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
-                                                            actions, enc_noise, fm_noise)
+                                                            actions, enc_noise, fm_noise, enc_latents)
         if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
             params = [p for _, p in self.hot_path_named_parameters()]
-            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, *params)
+            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, enc_latents, *params)
         else:
             _, _, pw = self._infer_handles()
-            losses, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise,
-                                         fm_noise=fm_noise)
+            losses = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise,
+                                      fm_noise=fm_noise, enc_latents=enc_latents.detach() if enc_latents is not None else None)[0]
             loss = losses[0]
         vals = losses.detach().cpu().tolist()
         metrics = {"loss": vals[1], "flow_loss": vals[1]}   # FM.compute_loss's own 'loss' entry is the flow loss (flow_matchers.py:39)
