@@ -162,6 +162,9 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
  * (*status - 1) and x_out is NOT valid (cannot happen while the launch's <= 256 workgroups are resident; the bound only
  * guarantees that the kernel always ends).  VITA_NO_PERSISTENT=1 in the environment selects the per-launch path. */
 int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status);
+/* the same word for the workspace of vita_generate_actions_f32 (its solve runs in one launch at serving batches, B <= 64, and at
+ * chip-filling ones): != 0 means that call's actions are NOT valid */
+int vita_generate_actions_status(const vita_flownet_weights* fw, int32_t B, int32_t num_steps, const void* workspace, int32_t* status);
 /* process-wide switch between the persistent launch (1, default unless VITA_NO_PERSISTENT=1) and the per-launch path (0);
  * returns the previous setting.  Both produce the same bits. */
 int vita_ode_sample_set_persistent(int32_t on);

@@ -113,6 +113,7 @@ def test_generate_actions_other_tasks_and_long_solves(task, O, A, B, K):
     ow, ob = sd["obs_encoder.weight"].to(DEV), sd["obs_encoder.bias"].to(DEV)
     obs = torch.randn(B, O, generator=torch.Generator().manual_seed(B + K)).to(DEV)
     a, lat = ops.generate_actions(ow, ob, fw, dw, obs, K, return_latents=True)
+    assert ops.generate_actions_status(fw, dw, B, K, DEV) == 0
     ops.set_persistent_sampler(False)
     b, latb = ops.generate_actions(ow, ob, fw, dw, obs, K, return_latents=True)
     torch.cuda.synchronize()

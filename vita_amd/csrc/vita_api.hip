@@ -412,6 +412,13 @@ int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num
     return VITA_OK;
 }
 
+int vita_generate_actions_status(const vita_flownet_weights* fw, int32_t B, int32_t num_steps, const void* workspace, int32_t* status) {
+    VITA_REQUIRE(fw && workspace && status && B > 0 && num_steps > 0, "vita_generate_actions_status: bad arguments");
+    // the solve's carve starts behind the latent rows (generate_actions_run)
+    const char* rest = static_cast<const char*>(workspace) + (((size_t)B * fw->D * 4 + 255) & ~size_t(255));
+    return vita_ode_sample_status(fw, B, num_steps, rest, status);
+}
+
 size_t vita_consistency_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {
     if (!w || B <= 0 || num_steps <= 0) return 0;
     return carve_flow(nullptr, w, B, num_steps, true, false).bytes;

@@ -246,6 +246,19 @@ def ode_sample_status(fw: FlowNetHandle, B: int, num_steps: int, device) -> int:
     return int(st.value)
 
 
+def generate_actions_status(fw: FlowNetHandle, dw: "DecoderHandle", B: int, num_steps: int, device) -> int:
+    """vita_generate_actions_status for the cached workspace the last generate_actions on `device` used (synchronises):
+    0 = its in-launch sampler completed (or it ran launch by launch), != 0 = a bounded hand-off wait ran out and the actions
+    are not valid."""
+    lib = L.load()
+    torch.cuda.synchronize(device)
+    nbytes = lib.vita_generate_actions_workspace_bytes(C.byref(fw.w), C.byref(dw.w), B, num_steps)
+    ws = workspace(torch.device(device), nbytes)
+    st = C.c_int32(0)
+    L.check(lib.vita_generate_actions_status(C.byref(fw.w), B, num_steps, ws.data_ptr(), C.byref(st)), "vita_generate_actions_status")
+    return int(st.value)
+
+
 def set_persistent_sampler(on: bool) -> bool:
     """Process-wide switch of vita_ode_sample_f32 / vita_generate_actions_f32 between the persistent launch and the
     per-launch path; returns the previous setting."""
