@@ -717,7 +717,8 @@ class VitaPolicy(nn.Module):
     @torch.no_grad()
     def select_action(self, batch):
         """vita_policy.py:210-220."""
-        self.eval()
+        if self.training:       # the reference calls eval() on every step; walking the module tree costs more host time than the solve's launch
+            self.eval()
         keep = list(self.config.task.image_keys) + [self.config.task.state_key, getattr(self.observer, "feature_key", None)]
         batch = {k: v.unsqueeze(1) for k, v in batch.items() if k in keep}
         batch = self.normalize_inputs(batch)
