@@ -74,7 +74,8 @@ class PolicyTrainer:
         t0 = time.perf_counter()
         net, c = self.network, self.config
         batch = {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in batch.items()}
-        net.train()
+        if not net.training:
+            net.train()
         batch = net.normalize_inputs(batch)
         batch = net.normalize_targets(batch)
         net.loss_and_grads(batch, t=t, pair_i=pair_i, pair_j=pair_j, grad_ready_events=self.events if self.overlap else None,
