@@ -388,7 +388,22 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
     int32_t grad_ready_layers;     /* 1: `grad_ready` holds 3 + L events; entry 3 + l is recorded when the gradients of
                                       flow_net.layers.l.mlp.{fc1,fc2}.{weight,bias} are final (their stacked weight-gradient GEMMs run
                                       layer by layer after the input-gradient chains), so a data-parallel caller can start that
-                                      layer's all-reduce while the following layers' weight gradients are still being computed */
+                                      layer's all-reduce while the following layers' weight gradients are still being computed.
+                                      The events are then recorded in the order 0, 2, 1, 3, .., 3 + L - 1 and mean: (0) the decoder's,
+                                      (2) the encoders' and obs_encoder's gradients and d_obs_features, (1) the flow net's OTHER than
+                                      the layers' mlp weights, (3 + l) layer l's — big buckets first, so that only one layer's
+                                      gradients (8 MB at H = 512) become final at the very end of the call.  Same bits either way */
+    int32_t external_decoder;      /* 1: the action decoder is the caller's own module (any: the reference's CNNActionDecoder /
+                                      CNNAttentionActionDecoder, action_vae.py:232-387 ...), vita_compute_loss_f32 with fp32 GEMMs
+                                      only.  Of `dec` only D, OUT and in_w are read: in_w of the weights descriptor is a (2B, D)
+                                      buffer that RECEIVES [pred; z1] (the sampler's result, zeros when that branch is off, and the
+                                      action latents), in_w of the gradient descriptor is the (2B, D) buffer that SUPPLIES
+                                      d (caller's terms) / d [pred; z1].  The reconstruction terms (vita_policy.py:174-187) are then
+                                      the caller's: losses[FLOW_RECON], [ENC_RECON] stay 0 and TOTAL is the sum of the other terms.
+                                      The step takes two calls on the same workspace: grads = NULL (forward; writes the latents),
+                                      then — after the caller's decoder has produced its gradient — resume_backward = 1 with grads */
+    int32_t resume_backward;       /* 1 (external_decoder only, grads != NULL): run only the backward pass of the forward the previous
+                                      call on this workspace, stream and arguments enqueued; `losses` is left as that call wrote it */
 } vita_loss_config;
 
 enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_LOSS_FLOW_RECON = 3, VITA_LOSS_ENC_RECON = 4,
@@ -416,7 +431,7 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
  *   (the ResNet backbone is in the reference's single AdamW group, vita_policy.py:222-229).
  * grad_ready: NULL or 3 hipEvent_t recorded on `stream` when (0) the decoder's, (1) the flow net's, (2) every
  *   gradient is final — the points at which a data-parallel caller starts that bucket's all-reduce; with
- *   cfg->grad_ready_layers, 3 + L events (see vita_loss_config). */
+ *   cfg->grad_ready_layers, 3 + L events in a different order and with narrower meanings (see vita_loss_config). */
 size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B);
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t,

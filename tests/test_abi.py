@@ -43,7 +43,7 @@ def test_struct_layouts_match_the_header(tmp_path):
         'offsetof(vita_linear_args, act_grad_z), sizeof(vita_meanflow_weights), offsetof(vita_meanflow_weights, u_w), '
         'sizeof(vita_meanflow_loss_config), offsetof(vita_meanflow_loss_config, kl_weight), offsetof(vita_meanflow_loss_config, use_imf), '
         'sizeof(vita_meanflow_policy_weights), offsetof(vita_meanflow_policy_weights, dec), sizeof(vita_bf16_weights), '
-        'offsetof(vita_bf16_weights, dec_fc2_w), offsetof(vita_loss_config, side_streams)); return 0;}\n')
+        'offsetof(vita_bf16_weights, dec_fc2_w), offsetof(vita_loss_config, resume_backward)); return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
                    check=True)
@@ -55,7 +55,7 @@ def test_struct_layouts_match_the_header(tmp_path):
             _lib.LinearArgs.act_grad_z.offset, ctypes.sizeof(_lib.MeanFlowWeights), _lib.MeanFlowWeights.u_w.offset,
             ctypes.sizeof(_lib.MeanFlowLossConfig), _lib.MeanFlowLossConfig.kl_weight.offset, _lib.MeanFlowLossConfig.use_imf.offset,
             ctypes.sizeof(_lib.MeanFlowPolicyWeights), _lib.MeanFlowPolicyWeights.dec.offset, ctypes.sizeof(_lib.Bf16Weights),
-            _lib.Bf16Weights.dec_fc2_w.offset, _lib.LossConfig.side_streams.offset]
+            _lib.Bf16Weights.dec_fc2_w.offset, _lib.LossConfig.resume_backward.offset]
     assert got == want
 
 

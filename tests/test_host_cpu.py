@@ -235,8 +235,9 @@ def test_bench_self_launches_one_process_per_gpu():
 
 
 def test_reduce_plan_covers_the_flat_buffer_once_in_firing_order():
-    """The data-parallel reduce plan: every hot-path parameter in exactly one segment; decoder first, then one segment per
-    flow-net layer's fc1 / fc2 gradients (events 3 + l), then the rest of the flow net, then the encoders."""
+    """The data-parallel reduce plan: every hot-path parameter in exactly one segment; decoder first, then the encoders, then
+    the rest of the flow net, then one segment per flow-net layer's fc1 / fc2 gradients (events 3 + l) — the order in which
+    vita_compute_loss_f32 records the events under grad_ready_layers."""
     import torch
     from vita_amd.config import default_config
     from vita_amd.policy import VitaPolicy
@@ -251,7 +252,10 @@ def test_reduce_plan_covers_the_flat_buffer_once_in_firing_order():
     assert bool((cover == 1).all())
     L_ = cfg.policy.flow_net.num_layers
     evs = [ev for _, _, ev in plan]
-    assert evs[0] == 0 and evs[-1] == 2 and evs[1:1 + L_] == [3 + l for l in range(L_)] and set(evs[1 + L_:-1]) == {1}
+    assert evs[0] == 0 and evs[-L_:] == [3 + l for l in range(L_)]
+    mid = evs[1:-L_]
+    n2 = mid.count(2)
+    assert n2 >= 1 and set(mid[:n2]) == {2} and set(mid[n2:]) == {1}
     H = cfg.policy.flow_net.hidden_dim
     per_layer = 2 * H * 4 * H + 4 * H + H          # fc1 (4H x H) + fc2 (H x 4H) + their biases
     assert all(hi - lo == per_layer for lo, hi, ev in plan if ev >= 3)

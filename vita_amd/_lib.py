@@ -104,6 +104,7 @@ class LossConfig(C.Structure):
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
         ("kl_weight", C.c_float), ("gemm_bf16", C.c_int32),
         ("fm_kind", C.c_int32), ("fm_sigma", C.c_float), ("side_streams", C.c_int32), ("grad_ready_layers", C.c_int32),
+        ("external_decoder", C.c_int32), ("resume_backward", C.c_int32),
     ]
 
 

@@ -399,22 +399,27 @@ int flow_eval_bwd(const FlowCtx& c, int e, const float* mod, int64_t ld_mod, flo
 
 // One wgrad GEMM + one column-sum per weight over the E*B stacked rows.
 // layer_ready: NULL, or L events; entry l is recorded when layers.l.mlp.{fc1,fc2}.{weight,bias} gradients are final
-int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs_part, void* const* layer_ready = nullptr) {
+// parts: kWgOuter = output / input projections and the final norm, kWgLayers = the hidden layers (both by default)
+enum { kWgOuter = 1, kWgLayers = 2 };
+int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs_part, void* const* layer_ready = nullptr,
+                      int parts = kWgOuter | kWgLayers) {
     const vita_flownet_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, L = w->L, R = c.E * c.B;
-    VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
-    VITA_TRY(vita_colsum_f32(c.f.DV, D, R, D, cs_part, mut(g.out_b), 0, c.st));
-    VITA_TRY(vita_colsum_f32(c.f.RN, H, R, H, cs_part, mut(g.norm_w), 0, c.st));
-    VITA_TRY(vita_colsum_f32(c.f.DHNF, H, R, H, cs_part, mut(g.norm_b), 0, c.st));
-    for (int l = 0; l < L; ++l) {
+    if (parts & kWgOuter) {
+        VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
+        VITA_TRY(vita_colsum_f32(c.f.DV, D, R, D, cs_part, mut(g.out_b), 0, c.st));
+        VITA_TRY(vita_colsum_f32(c.f.RN, H, R, H, cs_part, mut(g.norm_w), 0, c.st));
+        VITA_TRY(vita_colsum_f32(c.f.DHNF, H, R, H, cs_part, mut(g.norm_b), 0, c.st));
+        VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
+        VITA_TRY(vita_colsum_f32(c.f.DH0, H, R, H, cs_part, mut(g.in_b), 0, c.st));
+    }
+    for (int l = 0; l < L && (parts & kWgLayers); ++l) {
         VITA_TRY(gemm_f32(wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
         VITA_TRY(vita_colsum_f32(c.Y2(l, 0), H, R, H, cs_part, mut(g.fc2_b[l]), 0, c.st));
         VITA_TRY(gemm_f32(wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
         VITA_TRY(vita_colsum_f32(c.U(l, 0), FF, R, FF, cs_part, mut(g.fc1_b[l]), 0, c.st));
         if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
     }
-    VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
-    VITA_TRY(vita_colsum_f32(c.f.DH0, H, R, H, cs_part, mut(g.in_b), 0, c.st));
     return VITA_OK;
 }
 
@@ -597,7 +602,7 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     }
     s.wt = (train && B >= (size_t)kWtMinRows) ? c.take(wt_floats(&w.flow, nullptr, w.dec, w.enc)) : nullptr;
     s.flow = carve_flow_train(c, w.flow, B, K, train);
-    s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
+    if (!cfg.external_decoder) s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
     else if (w.enc.kind == VITA_ENC_CNN) s.cnn = carve_cnn(c, w.enc, B, train);
     s.bytes = c.off;
@@ -626,11 +631,13 @@ int check_enc_weights(const vita_encoder_weights* w, const char* who) {
     return VITA_OK;
 }
 
-int check_policy(const vita_policy_weights* w, const char* who) {
+int check_policy(const vita_policy_weights* w, const char* who, bool external_decoder = false) {
     VITA_REQUIRE(w != nullptr, "%s: null weights", who);
     VITA_REQUIRE(w->O > 0 && w->obs_w && w->obs_b, "%s: bad obs_encoder", who);
     VITA_TRY(check_flow_weights(&w->flow, who));
-    VITA_TRY(check_dec_weights(&w->dec, who));
+    if (external_decoder) VITA_REQUIRE(w->dec.D > 0 && w->dec.OUT > 0 && w->dec.in_w != nullptr,
+                                       "%s: an external decoder needs D, OUT and the (2B, D) latents buffer in dec.in_w", who);
+    else VITA_TRY(check_dec_weights(&w->dec, who));
     VITA_TRY(check_enc_weights(&w->enc, who));
     VITA_REQUIRE(w->flow.D == w->dec.D && w->flow.D == w->enc.D, "%s: latent dims differ (flow %d, decoder %d, encoder %d)", who, w->flow.D,
                  w->dec.D, w->enc.D);
@@ -660,6 +667,15 @@ int zero_encoder_grads(const vita_encoder_weights& g, hipStream_t st) {
     return VITA_OK;
 }
 
+// the caller's own decoder (vita_loss_config.external_decoder): a descriptor whose decoder owns nothing
+vita_policy_weights without_decoder(const vita_policy_weights& w) {
+    vita_policy_weights wl = w;
+    wl.dec = vita_decoder_weights{};
+    wl.dec.D = w.dec.D;
+    wl.dec.OUT = w.dec.OUT;
+    return wl;
+}
+
 int encoder_fwd(const vita_encoder_weights& w, const StepWs& s, const float* actions, float* z1, int64_t ldz, int B, hipStream_t st) {
     if (w.kind == VITA_ENC_EXTERNAL) {       // the latents were computed by the caller's module (contiguous (B, D) rows)
         VITA_CHECK_HIP(hipMemcpy2DAsync(z1, (size_t)ldz * 4, w.proj_w, (size_t)w.D * 4, (size_t)w.D * 4, (size_t)B, hipMemcpyDeviceToDevice, st));
@@ -682,6 +698,10 @@ extern "C" {
 
 size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B) {
     if (!w || !cfg || B <= 0) return 0;
+    if (cfg->external_decoder) {
+        const vita_policy_weights wl = without_decoder(*w);
+        return carve_step(nullptr, wl, *cfg, (size_t)B, true).bytes;
+    }
     return carve_step(nullptr, *w, *cfg, (size_t)B, true).bytes;
 }
 
@@ -690,9 +710,22 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
                           const int64_t* pair_j, const float* fm_noise, const float* enc_noise, int32_t B, float* losses, float* d_obs_features, int64_t ld_dobs,
                           void* const* grad_ready, void* workspace, size_t workspace_bytes, vita_stream_t stream) {
     const char* who = "vita_compute_loss_f32";
-    VITA_TRY(check_policy(w, who));
-    if (grads) VITA_TRY(check_policy(grads, "vita_compute_loss_f32 (grads)"));
     VITA_REQUIRE(cfg != nullptr, "%s: null config", who);
+    const bool ext_dec = cfg->external_decoder != 0, resume = cfg->resume_backward != 0;
+    VITA_TRY(check_policy(w, who, ext_dec));
+    if (grads) VITA_TRY(check_policy(grads, "vita_compute_loss_f32 (grads)", ext_dec));
+    VITA_REQUIRE(!ext_dec || cfg->gemm_bf16 == 0, "%s: an external decoder is built for the fp32 step only", who);
+    VITA_REQUIRE(ext_dec ? (resume == (grads != nullptr)) : !resume,
+                 "%s: with an external decoder the call is forward-only (grads NULL) or resume_backward with grads; resume_backward needs one", who);
+    // external decoder: dec.in_w of the two descriptors carries [pred; z1] out and d loss / d [pred; z1] in; nothing else of it is used
+    float* const lat_out = ext_dec ? const_cast<float*>(w->dec.in_w) : nullptr;
+    const float* const dlat_in = (ext_dec && grads) ? grads->dec.in_w : nullptr;
+    vita_policy_weights w_local, g_local;
+    if (ext_dec) {
+        w_local = without_decoder(*w);
+        w = &w_local;
+        if (grads) { g_local = without_decoder(*grads); grads = &g_local; }
+    }
     VITA_REQUIRE(!cfg->decode_flow_latents || cfg->num_steps >= 1, "%s: num_steps must be >= 1 (got %d)", who, cfg->num_steps);
     VITA_REQUIRE(cfg->consistency_weight >= 0.f && cfg->enc_recon_weight >= 0.f && cfg->flow_recon_weight >= 0.f, "%s: negative loss weight", who);
     VITA_REQUIRE(cfg->enc_contrastive_weight >= 0.f && cfg->flow_contrastive_weight >= 0.f && cfg->temperature >= 0.f,
@@ -724,8 +757,8 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     const int T = K > 0 ? (ride ? 2 * B + K - 1 : B + K) : B;
     const int step_row0 = ride ? 2 * B - 1 : B;                // time-path row of Euler step k: step_row0 + k
     const bool do_cons = do_sample && cfg->consistency_weight > 0.f;
-    const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f;
-    const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd;                                                           // :183
+    const bool dec_pred = do_sample && cfg->flow_recon_weight > 0.f && !ext_dec;   // external decoder: its terms are the caller's
+    const bool dec_enc = cfg->enc_recon_weight > 0.f && !fd && !ext_dec;                                               // :183
     const bool nce_enc = cfg->enc_contrastive_weight > 0.f;
     const bool nce_flow = do_sample && cfg->flow_contrastive_weight > 0.f;
     const float tau = cfg->temperature > 0.f ? cfg->temperature : 0.07f;
@@ -742,6 +775,18 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     const bool vae = w->enc.variational != 0;
     const bool do_kl = vae && !fe && !(fe && fd) && cfg->kl_weight > 0.f;                                               // :142-146
 
+    auto step_mod = [&](int k) { return s.flow.mod + (size_t)(step_row0 + k) * ldm; };   // one broadcast row per step
+    const bool plain_cfm = cfg->fm_kind == VITA_FM_CONDITIONAL && cfg->fm_sigma == 0.f;
+    const float dt = K > 0 ? (float)(1.0 / (double)K) : 0.f;
+    // both decoder calls as one batch of rows [r0, r0 + M) of ZZ = [pred; z1]      :174-187
+    const Stack dec = stack_of(w->dec);
+    const int r0 = dec_pred ? 0 : B;
+    const int M = (dec_pred ? B : 0) + (dec_enc ? B : 0);
+    const int enc_row = dec_pred ? B : 0;   // row of the decoder batch where dec(z1) starts
+    const int64_t n_rec = (int64_t)B * OUT;
+
+    // resume_backward: the forward ran in an earlier call on this workspace (everything the backward reads is still there)
+    if (!resume) {
     // loss weights as device scalars (seeds of the backward pass) ; zero the outputs
     const float seeds[6] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight, cfg->enc_contrastive_weight,
                             cfg->flow_contrastive_weight};
@@ -765,15 +810,12 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         VITA_TRY(launch_step_times(s.flow.ts + step_row0, K, st));   // ts[step_row0 + k] = k/K (k = 0 closes the zero block)
     }
     VITA_TRY(time_path_fwd(fc, T));
-    auto step_mod = [&](int k) { return s.flow.mod + (size_t)(step_row0 + k) * ldm; };   // one broadcast row per step
     // flow-matching loss, flow_matchers.py:30-36
-    const bool plain_cfm = cfg->fm_kind == VITA_FM_CONDITIONAL && cfg->fm_sigma == 0.f;
     if (plain_cfm) VITA_TRY(vita_cfm_interpolate_f32(s.z0, z1, t, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
     else VITA_TRY(vita_fm_interpolate_f32(cfg->fm_kind, (double)cfg->fm_sigma, s.z0, z1, t, fm_noise, pair_i, pair_j, fc.X(0), s.ut, B, D, st));
     // The flow-matching evaluation and Euler step 0 are independent and their rows are adjacent in every stacked buffer:
     // they run as ONE 2B-row pass with per-row modulation (one evaluation's worth of launches less per step, forward and
     // backward; at the default B = 128 the step is launch-bound).  Only out_proj differs (v vs x + dt*v) and stays per evaluation.
-    const float dt = K > 0 ? (float)(1.0 / (double)K) : 0.f;
     if (do_sample) VITA_CHECK_HIP(hipMemcpyAsync(fc.X(1), s.z0, (size_t)B * D * 4, hipMemcpyDeviceToDevice, st));
     if (ride) {
         VITA_TRY(flow_trunk_fwd(fc, 0, 2 * B, s.flow.mod, ldm));
@@ -794,12 +836,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         if (do_cons) VITA_TRY(vita_mse_loss_fwd_f32(pred, z1, (int64_t)B * D, s.loss_part, losses + VITA_LOSS_CONSISTENCY, st));   // :162-165
         if (nce_flow) VITA_TRY(nce_forward(s.z0, D, pred, D, B, D, tau, losses + VITA_LOSS_FLOW_CONTRASTIVE, s.nce_flow, st));   // :167-172
     }
-    // both decoder calls as one batch of rows [r0, r0 + M) of ZZ = [pred; z1]      :174-187
-    const Stack dec = stack_of(w->dec);
-    const int r0 = dec_pred ? 0 : B;
-    const int M = (dec_pred ? B : 0) + (dec_enc ? B : 0);
-    const int enc_row = dec_pred ? B : 0;   // row of the decoder batch where dec(z1) starts
-    const int64_t n_rec = (int64_t)B * OUT;
+    if (ext_dec) {   // hand [pred; z1] to the caller's decoder (pred rows are zeros when the sampler branch is off)
+        VITA_CHECK_HIP(hipMemcpyAsync(lat_out, s.ZZ, (size_t)2 * B * D * 4, hipMemcpyDeviceToDevice, st));
+        if (!do_sample) VITA_CHECK_HIP(hipMemsetAsync(lat_out, 0, (size_t)B * D * 4, st));
+    }
     if (M > 0) {
         VITA_TRY(stack_fwd(dec, s.dec, s.ZZ + (size_t)r0 * D, D, M, nullptr, st));
         auto recon = cfg->recon_l1 ? vita_l1_loss_fwd_f32 : vita_mse_loss_fwd_f32;
@@ -810,6 +850,7 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
                            dec_enc ? cfg->enc_recon_weight : 0.f, nce_enc ? cfg->enc_contrastive_weight : 0.f,
                            nce_flow ? cfg->flow_contrastive_weight : 0.f, do_kl ? cfg->kl_weight : 0.f};
     VITA_TRY(launch_weighted_sum(losses, wsum, 8, losses + VITA_LOSS_TOTAL, st));
+    }   // !resume
     if (!train) return VITA_OK;
 
     // ---- backward -----------------------------------------------------------------------------
@@ -820,9 +861,15 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     };
     void* const* layer_ready = (grad_ready && cfg->grad_ready_layers) ? grad_ready + 3 : nullptr;
     // decoder: dZZ = d loss / d [pred; z1] through the reconstruction terms
-    if (!dec_pred) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ, 0, (size_t)B * D * 4, st));
-    if (!dec_enc) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ + (size_t)B * D, 0, (size_t)B * D * 4, st));
-    if (M > 0) {
+    if (ext_dec) {   // d (the caller's decoder terms) / d [pred; z1]
+        VITA_CHECK_HIP(hipMemcpyAsync(s.dZZ, dlat_in, (size_t)2 * B * D * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+        if (!dec_pred) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ, 0, (size_t)B * D * 4, st));
+        if (!dec_enc) VITA_CHECK_HIP(hipMemsetAsync(s.dZZ + (size_t)B * D, 0, (size_t)B * D * 4, st));
+    }
+    if (ext_dec) {
+        // nothing of the decoder's is computed here
+    } else if (M > 0) {
         auto recon_bwd = cfg->recon_l1 ? vita_l1_loss_bwd_f32 : vita_mse_loss_bwd_f32;
         if (dec_pred) VITA_TRY(recon_bwd(s.dec.out, actions, n_rec, s.consts + 2, s.dec.dOut, nullptr, 0, st));
         if (dec_enc)
@@ -928,18 +975,37 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
             VITA_TRY(encoders_bwd(s.cs_side[2], side->s[2]));
             VITA_CHECK_HIP(hipEventRecord(side->join[2], side->s[2]));
         }
-        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready));
-        VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
-        VITA_TRY(record(1));
-        VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[2], 0));
+        if (layer_ready) {   // the order of the single-stream branch below: encoders, rest of the flow net, layers
+            VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[2], 0));
+            VITA_TRY(record(2));
+            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, nullptr, kWgOuter));
+            VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
+            VITA_TRY(record(1));
+            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready, kWgLayers));
+        } else {
+            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
+            VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
+            VITA_TRY(record(1));
+            VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[2], 0));
+        }
         if (dec_on_side) VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[0], 0));
+        if (!layer_ready) VITA_TRY(record(2));
+    } else if (layer_ready) {
+        // per-layer events: largest buckets first and a small one last, so that what a data-parallel caller still has to
+        // all-reduce when the backward ends is one layer's 8 MB, not the encoders' 18 MB (event order 0, 2, 1, 3 .. 3+L-1)
+        VITA_TRY(encoders_bwd(s.cs_part, st));
+        VITA_TRY(record(2));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, nullptr, kWgOuter));
+        VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
+        VITA_TRY(record(1));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready, kWgLayers));
     } else {
-        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
         VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
         VITA_TRY(record(1));
         VITA_TRY(encoders_bwd(s.cs_part, st));
+        VITA_TRY(record(2));
     }
-    VITA_TRY(record(2));
     return VITA_OK;
 }
 

@@ -3,10 +3,10 @@
   * ODE inference: rows are independent (no op on the path mixes rows; LayerNorm is per row), so rank r takes the
     contiguous rows shard_range(B, r, N) and there is NO data-path collective.
   * Training: data parallel.  Each rank's vita_compute_loss_f32 writes the gradient of ITS shard's mean loss into a
-    flat fp32 buffer laid out [decoder | flow net | encoders] — the order in which the hand-written backward finishes
-    them — and records an event per segment; BucketReducer all-reduces a segment on a side stream as soon as its event
-    fires, so the decoder's and the flow net's reductions overlap the rest of the backward.  The sum is turned into the
-    mean (x 1/N) inside the fused clip+AdamW+EMA kernel, not by a separate pass.
+    flat fp32 buffer laid out [decoder | flow net: rest, then layer by layer | encoders] and records an event per
+    segment (VitaPolicy.reduce_plan gives the order they fire in); BucketReducer all-reduces a segment on a side stream
+    as soon as its event fires, so the reductions overlap the rest of the backward.  The sum is turned into the mean
+    (x 1/N) inside the fused clip+AdamW+EMA kernel, not by a separate pass.
 
 The reducer works on any torch.distributed backend: "nccl" (= RCCL over xGMI on the GPU box) and "gloo" on CPU
 tensors, which is how the tests cover world_size 2 without GPUs.

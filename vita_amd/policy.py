@@ -382,16 +382,28 @@ class VitaPolicy(nn.Module):
 
     # -- parameter plumbing --------------------------------------------------------------------------
     def hot_path_named_parameters(self):
-        """(name, parameter) of the trainable hot-path tensors in flat-buffer order."""
+        """(name, parameter) of the trainable hot-path tensors in flat-buffer order: decoder, flow net (the layers' mlp
+        weights last, layer by layer, so that each gradient-ready event of reduce_plan covers ONE contiguous range and is one
+        all-reduce), encoders."""
         named = dict(self.named_parameters())
         out = []
         for prefixes in self.BUCKET_PREFIXES:
+            group = []
             for k, p in named.items():
                 if self.external_encoder and k.startswith("action_encoder."):
                     continue        # a torch module beside the fused path: its gradients come through autograd
                 if k.startswith(prefixes) and p.requires_grad:
-                    out.append((k, p))
+                    group.append((k, p))
+            group.sort(key=lambda kp: self._layer_mlp_index(kp[0]))     # stable: module order within each class
+            out += group
         return out
+
+    def _layer_mlp_index(self, key: str) -> int:
+        """l for flow_net.layers.l.mlp.* of the default flow net (the tensors behind gradient-ready event 3 + l), else -1."""
+        parts = key.split(".")
+        if not self.mean_flow and len(parts) > 3 and parts[0] == "flow_net" and parts[1] == "layers" and parts[3] == "mlp":
+            return int(parts[2])
+        return -1
 
     def frozen_prefixes(self) -> tuple:
         """Modules that receive no gradient under the freeze flags (vita_policy.py:119,153,174,183): the reference leaves
@@ -417,11 +429,11 @@ class VitaPolicy(nn.Module):
         return out
 
     def reduce_plan(self):
-        """[(lo, hi, event)] over the flat gradient buffer, in the order the events fire inside the fused backward: the
-        decoder (event 0); then, for the default flow net, each layer's mlp.fc1 / mlp.fc2 gradients (event 3 + l: their
-        stacked weight-gradient GEMMs run layer by layer, vita_loss_config.grad_ready_layers); the rest of the flow net
-        (event 1: input / output projections, norm, time path, modulators); the encoders (event 2).  The MeanFlow step
-        records events 0..2 only."""
+        """[(lo, hi, event)] over the flat gradient buffer, in the order the events fire inside the fused backward
+        (vita_loss_config.grad_ready_layers): the decoder (event 0); the encoders (event 2); the flow net other than the
+        layers' mlp weights (event 1: input / output projections, norm, time path, modulators); then each layer's mlp.fc1 /
+        mlp.fc2 gradients (event 3 + l, their stacked weight-gradient GEMMs run layer by layer) — the big buckets early, one
+        layer's 8 MB last.  The MeanFlow step records events 0, 1, 2 in that order."""
         plan, off = [], 0
         named = self.hot_path_named_parameters()
         for k, p in named:
@@ -429,10 +441,8 @@ class VitaPolicy(nn.Module):
             if k.startswith("action_decoder."):
                 ev = 0
             elif k.startswith("flow_net."):
-                ev = 1
-                parts = k.split(".")
-                if not self.mean_flow and parts[1] == "layers" and parts[3] == "mlp":
-                    ev = 3 + int(parts[2])
+                l = self._layer_mlp_index(k)
+                ev = 3 + l if l >= 0 else 1
             else:
                 ev = 2
             if plan and plan[-1][2] == ev and plan[-1][1] == off:
@@ -440,7 +450,7 @@ class VitaPolicy(nn.Module):
             else:
                 plan.append((off, off + n, ev))
             off += n
-        order = {0: 0, 1: 10 ** 6, 2: 10 ** 6 + 1}
+        order = {0: 0, 1: 2, 2: 1} if any(ev >= 3 for _, _, ev in plan) else {}   # 3 events only: they fire 0, 1, 2
         plan.sort(key=lambda seg: (order.get(seg[2], seg[2]), seg[0]))
         return plan
 
