@@ -560,6 +560,25 @@ def generate_actions(sd: SD, obs_features: Tensor, num_steps: int, pred_horizon:
     return simple_action_decode(sd, z, pred_horizon, action_dim)
 
 
+def cnn_action_decode(sd: SD, z: Tensor, pred_horizon: int, hidden_dim: int, prefix: str = "action_decoder.") -> Tensor:
+    """CNNActionDecoder.forward, action_vae.py:284-298: latent_proj, view as (B, hidden, L0), ConvTranspose1d(k5, s2, p2,
+    output_padding 1) with ReLU between (none after the last), transpose to (B, T, A); linear interpolation to pred_horizon when
+    the length differs (:293-296)."""
+    x = F.linear(z, sd[prefix + "latent_proj.weight"], sd[prefix + "latent_proj.bias"])
+    x = x.view(z.shape[0], hidden_dim, -1)
+    n = 0
+    while f"{prefix}decoder.{2 * n}.weight" in sd:
+        n += 1
+    for i in range(n):
+        x = F.conv_transpose1d(x, sd[f"{prefix}decoder.{2 * i}.weight"], sd[f"{prefix}decoder.{2 * i}.bias"], stride=2, padding=2,
+                               output_padding=1)
+        if i < n - 1:
+            x = F.relu(x)
+    if x.shape[2] != pred_horizon:
+        x = F.interpolate(x, size=pred_horizon, mode="linear", align_corners=False)
+    return x.transpose(1, 2)
+
+
 def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, num_steps: int,
                  pair_i: Tensor | None = None, pair_j: Tensor | None = None,
                  consistency_weight: float = 1.0, enc_recon_weight: float = 0.5,
@@ -568,10 +587,13 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
                  decode_flow_latents: bool = True, sigma: float = 0.0,
                  freeze_encoder: bool = False, freeze_decoder: bool = False,
                  kl_weight: float = 0.0, enc_noise: Tensor | None = None,
-                 fm_kind: str = "conditional", fm_noise: Tensor | None = None, enc_latents: Tensor | None = None):
+                 fm_kind: str = "conditional", fm_noise: Tensor | None = None, enc_latents: Tensor | None = None,
+                 decoder=None):
     """VitaPolicy.compute_loss, vita_policy.py:112-189, from observer features on, with the
     (enc_latents: the action latents of an encoder that is not in `sd` — another encoder_type's module — instead of
     action_encode(sd, ...); everything downstream is unchanged)
+    (decoder: a callable latents (B, D) -> actions (B, T, A) that is not in `sd` — another decoder_type's module, e.g.
+    cnn_action_decode below — instead of simple_action_decode(sd, ...))
     freeze flags of :119,142-143,153,174,183.  A state dict whose action_encoder.latent_proj is
     2*latent_dim wide is the variational autoencoder (use_variational, :120-121,146-150):
     `enc_noise` is the posterior's randn_like draw (None = eval mode's deterministic posterior).
@@ -581,6 +603,7 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
     T, A = gt_actions.shape[1], gt_actions.shape[2]
     B = obs_features.shape[0]
     m = {}
+    decode = decoder if decoder is not None else (lambda z: simple_action_decode(sd, z, T, A))
     obs_latents = obs_encode(sd, obs_features)                                  # :114
     vae = enc_latents is None and is_variational(sd)
     if enc_latents is not None:
@@ -619,11 +642,11 @@ def compute_loss(sd: SD, obs_features: Tensor, gt_actions: Tensor, t: Tensor, nu
             loss = loss + flow_contrastive_weight * c
             m["flow_contrastive_loss"] = c
         if flow_recon_weight > 0 and not freeze_decoder:                        # :174
-            r = recon(simple_action_decode(sd, pred, T, A), gt_actions)
+            r = recon(decode(pred), gt_actions)
             m["flow_action_recon_loss"] = r
             loss = loss + flow_recon_weight * r
     if enc_recon_weight > 0 and not freeze_decoder:                             # :183-187
-        r = recon(simple_action_decode(sd, action_latents, T, A), gt_actions)
+        r = recon(decode(action_latents), gt_actions)
         m["enc_action_recon_loss"] = r
         loss = loss + enc_recon_weight * r
     m["loss"] = loss

@@ -48,6 +48,40 @@ def main():
         for n, p in ref.named_parameters():
             out[f"{tag}/grad/{n}"] = p.grad.contiguous()
         out[f"{tag}/dims"] = torch.tensor([HID, D, NH, T, A, NL, B])
+    # the variational encoder of action_vae.py:37-120 (use_variational + encoder_type transformer): posterior parameters
+    avae = G.load_by_path("ref_action_vae", "flare/networks/vita/action_vae.py")
+    HID, D, NH, T, A, NL, B = 64, 32, 8, 16, 7, 2, 5
+    torch.manual_seed(9)
+    ref = avae.TransformerActionEncoder(enc_hidden_dim=HID, latent_dim=D, num_heads=NH, pred_horizon=T, action_dim=A, num_layers=NL,
+                                        mlp_ratio=4.0, dropout=0.0)
+    with torch.no_grad():
+        g = torch.Generator().manual_seed(3)
+        for n, p in ref.named_parameters():
+            if p.dim() == 1:
+                p.add_(0.1 * torch.randn(p.shape, generator=g))
+    ref.train()
+    actions = torch.randn(B, T, A, generator=torch.Generator().manual_seed(5), requires_grad=True)
+    w = torch.randn(B, 2 * D, generator=torch.Generator().manual_seed(6))
+    post, z = ref(actions, deterministic=True)
+    assert torch.equal(z, post.mean) and torch.equal(post.parameters[:, :D], post.mean)
+    (post.parameters * w).sum().backward()
+    mine = TransformerActionEncoder(enc_hidden_dim=HID, latent_dim=D, num_heads=NH, pred_horizon=T, action_dim=A, num_layers=NL, variational=True)
+    mine.load_state_dict(ref.state_dict(), strict=True)
+    a2 = actions.detach().clone().requires_grad_(True)
+    p2 = mine(a2)
+    (p2 * w).sum().backward()
+    assert (p2 - post.parameters).abs().max().item() <= 1e-6 and (a2.grad - actions.grad).abs().max().item() <= 1e-6
+    # the posterior's sample / KL (models/dists.py) on these parameters, for the policy-side restatement
+    eps = torch.randn(B, D, generator=torch.Generator().manual_seed(8))
+    torch.manual_seed(123)
+    post_s = G.load_by_path("ref_dists", "flare/models/dists.py").DiagonalGaussianDistribution(post.parameters.detach())
+    for k, v in ref.state_dict().items():
+        out[f"vae/sd/{k}"] = v.contiguous()
+    out["vae/actions"], out["vae/w"], out["vae/params"], out["vae/d_actions"] = actions.detach(), w, post.parameters.detach(), actions.grad
+    out["vae/eps"], out["vae/sample"], out["vae/kl"] = eps, (post_s.mean + post_s.std * eps), post_s.kl()
+    for n, p in ref.named_parameters():
+        out[f"vae/grad/{n}"] = p.grad.contiguous()
+    out["vae/dims"] = torch.tensor([HID, D, NH, T, A, NL, B])
     save_file(out, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "transformer_encoder.safetensors"))
     print("ok", len(out), "tensors")
 

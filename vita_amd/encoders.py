@@ -105,11 +105,14 @@ class TransformerBlock(nn.Module):
 
 class TransformerActionEncoder(nn.Module):
     """action_ae.py:36-108: a CLS token + one token per action step, fixed sinusoidal positions, `num_layers` blocks, LayerNorm,
-    and the CLS output projected to the latent."""
+    and the CLS output projected to the latent.  variational=True is the encoder of action_vae.py:37-120 (`use_variational`
+    with `encoder_type: transformer`): the projection is 2 * latent_dim wide and forward returns those (B, 2 * latent_dim)
+    posterior parameters [mean | logvar]; the caller (VitaPolicy.compute_loss) samples and forms the KL term (models/dists.py)."""
 
     def __init__(self, enc_hidden_dim: int, latent_dim: int, num_heads: int, pred_horizon: int, action_dim: int, num_layers: int = 4,
-                 mlp_ratio: float = 4.0, dropout: float = 0.0):
+                 mlp_ratio: float = 4.0, dropout: float = 0.0, variational: bool = False):
         super().__init__()
+        self.variational = bool(variational)
         if float(dropout) != 0.0:
             raise NotImplementedError("TransformerActionEncoder: dropout > 0 is not built (vita.yaml ships 0.0)")
         self.cls_embed = nn.Embedding(1, enc_hidden_dim)
@@ -117,7 +120,7 @@ class TransformerActionEncoder(nn.Module):
         self.layers = nn.ModuleList([TransformerBlock(enc_hidden_dim, num_heads, mlp_ratio, rope_max_seq_length=pred_horizon + 1)
                                      for _ in range(num_layers)])
         self.norm = nn.LayerNorm(enc_hidden_dim)
-        self.latent_output_proj = nn.Linear(enc_hidden_dim, latent_dim)
+        self.latent_output_proj = nn.Linear(enc_hidden_dim, latent_dim * (2 if self.variational else 1))
         self.register_buffer("pos_embed", create_sinusoidal_pos_embedding(1 + pred_horizon, enc_hidden_dim).unsqueeze(0))
         for m in self.modules():        # action_ae.py:80-85
             if isinstance(m, nn.Linear):
@@ -125,7 +128,7 @@ class TransformerActionEncoder(nn.Module):
                 if m.bias is not None:
                     nn.init.zeros_(m.bias)
 
-    def forward(self, actions: torch.Tensor) -> torch.Tensor:      # (B, T, A) -> (B, latent_dim)
+    def forward(self, actions: torch.Tensor) -> torch.Tensor:      # (B, T, A) -> (B, latent_dim), or (B, 2 * latent_dim) when variational
         B = actions.shape[0]
         tokens = torch.cat([self.cls_embed.weight.unsqueeze(0).expand(B, -1, -1), self.action_input_proj(actions)], dim=1)
         x = tokens + self.pos_embed[:, :tokens.shape[1]]

@@ -860,9 +860,12 @@ class PolicyHandle:
     since the kernels write into them."""
 
     def __init__(self, sd: Mapping[str, Tensor], device, pred_horizon: int = 16, strict: bool = False,
-                 external_encoder_action_dim: Optional[int] = None):
+                 external_encoder_action_dim: Optional[int] = None, external_decoder_action_dim: Optional[int] = None):
         """external_encoder_action_dim: the action encoder is the caller's own module (VITA_ENC_EXTERNAL): `sd` holds no
-        action_encoder.* tensors, compute_loss takes the encoder's output as `enc_latents`."""
+        action_encoder.* tensors, compute_loss takes the encoder's output as `enc_latents`.
+        external_decoder_action_dim: the action decoder is the caller's own module (vita_loss_config.external_decoder): `sd`
+        holds no action_decoder.* tensors; compute_loss then runs as a forward call that returns [pred; z1] and a backward call
+        that takes d (decoder terms) / d [pred; z1]."""
         device = torch.device(device)
         self.device = device
         self.t = {}
@@ -872,7 +875,12 @@ class PolicyHandle:
         w.O = ow.shape[1]
         w.obs_w, w.obs_b = ow.data_ptr(), g("obs_encoder.bias").data_ptr()
         _fill_flow(w.flow, g, "flow_net.", sd)
-        _fill_dec(w.dec, g, "action_decoder.", sd)
+        self.external_decoder = external_decoder_action_dim is not None
+        self._step_ws = None        # external decoder: the workspace that lives from the forward call to the backward call
+        if self.external_decoder:
+            w.dec.D, w.dec.OUT = ow.shape[0], pred_horizon * int(external_decoder_action_dim)
+        else:
+            _fill_dec(w.dec, g, "action_decoder.", sd)
         if external_encoder_action_dim is not None:
             w.enc.kind, w.enc.A, w.enc.T, w.enc.D = L.ENC_EXTERNAL, int(external_encoder_action_dim), pred_horizon, ow.shape[0]
         else:
@@ -915,11 +923,16 @@ def _event_handles(events, who: str):
 
 def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t: Tensor, *, grads: Optional[PolicyHandle] = None,
                  pair_i=None, pair_j=None, need_dobs: bool = False, grad_ready_events=None, losses: Optional[Tensor] = None,
-                 enc_noise: Optional[Tensor] = None, fm_noise: Optional[Tensor] = None, enc_latents: Optional[Tensor] = None):
+                 enc_noise: Optional[Tensor] = None, fm_noise: Optional[Tensor] = None, enc_latents: Optional[Tensor] = None,
+                 dec_dlatents: Optional[Tensor] = None):
     """VitaPolicy.compute_loss (+ backward when `grads` is given), vita_policy.py:112-189.  Returns
     (losses (8,) device tensor indexed as _lib.LOSS_NAMES, d_obs_features or None).  No host sync.
     enc_latents: with an external action encoder (PolicyHandle(external_encoder_action_dim=...)) the (B, D) output of the
-    caller's module; the return value then has a third entry, d loss / d enc_latents (None without `grads`)."""
+    caller's module; the return value then has a third entry, d loss / d enc_latents (None without `grads`).
+    With an external action decoder (PolicyHandle(external_decoder_action_dim=...)) the step is two calls with the same
+    arguments: without `grads` the forward, whose return value ends with the (2B, D) latents [pred; z1] the caller decodes (the
+    reconstruction terms are the caller's; losses[TOTAL] is the sum of the others); then with `grads`, `losses` (left as the
+    forward wrote it) and dec_dlatents = d (caller's terms) / d latents, the backward alone."""
     lib = L.load()
     obs_features = _rows(obs_features, "compute_loss: obs_features")
     actions = _f32(actions, "compute_loss: actions").contiguous()
@@ -966,8 +979,40 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
             dlat = torch.empty((B, pw.D), dtype=torch.float32, device=dev)
             gdesc = L.PolicyWeights.from_buffer_copy(grads.w)
             gdesc.enc.proj_w = dlat.data_ptr()
+    latents = None
+    if pw.external_decoder:
+        if grads is not None and not grads.external_decoder:
+            raise L.VitaHipError("compute_loss: the gradient handle must be built with external_decoder_action_dim too")
+        cfg = L.LossConfig.from_buffer_copy(cfg)
+        cfg.external_decoder = 1
+        if wdesc is pw.w:
+            wdesc = L.PolicyWeights.from_buffer_copy(pw.w)
+        if grads is None:
+            if dec_dlatents is not None:
+                raise L.VitaHipError("compute_loss: dec_dlatents goes with the backward call (grads)")
+            latents = torch.empty((2 * B, pw.D), dtype=torch.float32, device=dev)
+            wdesc.dec.in_w = latents.data_ptr()
+        else:
+            if dec_dlatents is None or tuple(dec_dlatents.shape) != (2 * B, pw.D):
+                raise L.VitaHipError(f"compute_loss: the backward call of an external decoder needs dec_dlatents (2B, D) = ({2 * B}, {pw.D})")
+            dec_dlatents = _f32(dec_dlatents, "compute_loss: dec_dlatents").contiguous()
+            cfg.resume_backward = 1
+            wdesc.dec.in_w = dec_dlatents.data_ptr()     # not written by a backward call; the descriptor check wants it non-null
+            if gdesc is grads.w:
+                gdesc = L.PolicyWeights.from_buffer_copy(grads.w)
+            gdesc.dec.in_w = dec_dlatents.data_ptr()
+    elif dec_dlatents is not None:
+        raise L.VitaHipError("compute_loss: dec_dlatents goes with an external action decoder, and only with one")
     nbytes = lib.vita_compute_loss_workspace_bytes(C.byref(wdesc), C.byref(cfg), B)
-    ws = workspace(dev, nbytes)
+    if pw.external_decoder:     # the saved activations must survive until the backward call: a workspace of the handle's own
+        if grads is None:
+            if pw._step_ws is None or pw._step_ws.numel() < nbytes or pw._step_ws.device != dev:
+                pw._step_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        elif pw._step_ws is None or pw._step_ws.numel() < nbytes:
+            raise L.VitaHipError("compute_loss: the backward call of an external decoder must follow its forward call (same batch size)")
+        ws = pw._step_ws
+    else:
+        ws = workspace(dev, nbytes)
     L.check(lib.vita_compute_loss_f32(C.byref(wdesc), C.byref(gdesc) if gdesc is not None else None, C.byref(cfg),
                                       obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(),
                                       pair_i.data_ptr() if pair_i is not None else None,
@@ -976,9 +1021,10 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
                                       enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
                                       dobs.data_ptr() if dobs is not None else None, pw.O, ev, ws.data_ptr(), ws.numel(),
                                       _stream(obs_features)), "vita_compute_loss_f32")
-    if external:
-        return losses, dobs, dlat
-    return losses, dobs
+    out = (losses, dobs, dlat) if external else (losses, dobs)
+    if pw.external_decoder and grads is None:
+        out = out + (latents,)
+    return out
 
 
 class MeanFlowPolicyHandle:

@@ -22,6 +22,7 @@ from typing import Optional
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import _lib as L
 from . import ops
@@ -230,6 +231,48 @@ class _FusedLoss(torch.autograd.Function):
         return (None, dobs, None, None, None, None, None, None, dlat) + tuple(ctx.staged)
 
 
+class _FusedLossExternalDecoder(torch.autograd.Function):
+    """The fused step around an action decoder that is a torch module (vita_loss_config.external_decoder): forward = the
+    forward call, returning the partial loss (every term but the decoder's) and the latents [pred; z1] as a differentiable
+    output; backward = the resume_backward call, seeded with the incoming d / d latents.  The backward pass is linear in its
+    seeds, so it runs on d_latents / gout with unit loss seeds and the staged gradients are scaled by gout afterwards
+    (gout = 0 would lose the latents' part; autograd passes 1 for loss.backward())."""
+
+    @staticmethod
+    def forward(ctx, policy, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, enc_latents, *params):
+        pw, _, _ = policy._train_handles(stage=True)
+        obs_d = obs_features.detach()
+        lat_d = enc_latents.detach() if enc_latents is not None else None
+        out = ops.compute_loss(pw, policy._loss_cfg, obs_d, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise, fm_noise=fm_noise,
+                               enc_latents=lat_d)
+        losses, latents = out[0], out[-1]
+        ctx.policy, ctx.args = policy, (obs_d, actions, t, pair_i, pair_j, enc_noise, fm_noise, lat_d)
+        ctx.need_dobs = obs_features.requires_grad
+        ctx.need_dlat = enc_latents is not None and enc_latents.requires_grad
+        ctx.losses = losses
+        ctx.mark_non_differentiable(losses)
+        return losses[0].clone(), losses, latents
+
+    @staticmethod
+    def backward(ctx, gout, _, glat):
+        policy = ctx.policy
+        obs_d, actions, t, pair_i, pair_j, enc_noise, fm_noise, lat_d = ctx.args
+        pw, gw, gsd = policy._train_handles(stage=True)
+        if gout is None:
+            gout = torch.zeros((), dtype=torch.float32, device=obs_d.device)
+        scale = torch.where(gout != 0, gout, torch.ones_like(gout))
+        B = obs_d.shape[0]
+        dl = glat / scale if glat is not None else torch.zeros((2 * B, policy.latent_dim), dtype=torch.float32, device=obs_d.device)
+        out = ops.compute_loss(pw, policy._loss_cfg, obs_d, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j, need_dobs=ctx.need_dobs,
+                               losses=ctx.losses, enc_noise=enc_noise, fm_noise=fm_noise, enc_latents=lat_d, dec_dlatents=dl)
+        policy._cache["stage_buf"].mul_(scale)
+        frozen = policy.frozen_prefixes()
+        staged = [None if k.startswith(frozen) else gsd[k] for k, _ in policy.hot_path_named_parameters()]
+        dobs = out[1] * scale if out[1] is not None else None
+        dlat = out[2] * scale if (ctx.need_dlat and len(out) > 2 and out[2] is not None) else None
+        return (None, dobs, None, None, None, None, None, None, dlat) + tuple(staged)
+
+
 class _FusedMeanFlowLoss(torch.autograd.Function):
     """_FusedLoss for flow_matcher.name = 'mean': vita_compute_loss_meanflow_f32 (forward + backward in one call)."""
 
@@ -261,11 +304,16 @@ class VitaPolicy(nn.Module):
     # flat-buffer segment order = the order gradients become final in the backward pass (vita_loss_step.hip)
     BUCKET_PREFIXES = (("action_decoder.",), ("flow_net.",), ("action_encoder.", "obs_encoder."))
 
-    def __init__(self, config, stats, observer: Optional[nn.Module] = None, action_encoder: Optional[nn.Module] = None):
+    def __init__(self, config, stats, observer: Optional[nn.Module] = None, action_encoder: Optional[nn.Module] = None,
+                 action_decoder: Optional[nn.Module] = None):
         """action_encoder: an nn.Module mapping normalised actions (B, T, A) to latents (B, latent_dim) that replaces the
         configured one (for instance the reference's own module of a non-default encoder type).  It runs under torch autograd
         and meets the fused path at the latents (VITA_ENC_EXTERNAL, vita_amd/encoders.py); `encoder_type: transformer` builds
-        vita_amd.encoders.TransformerActionEncoder this way."""
+        vita_amd.encoders.TransformerActionEncoder this way.  Under `use_variational` the module returns the (B, 2 * latent_dim)
+        posterior parameters [mean | logvar]; compute_loss samples and adds the KL term (models/dists.py:4-35, vita_policy.py:146-150).
+        action_decoder: an nn.Module mapping latents (B, latent_dim) to normalised actions (B, T, A) that replaces the configured
+        one; the fused step then runs as a forward call and a backward call around it (vita_loss_config.external_decoder,
+        vita_amd/decoders.py).  `use_variational` with `decoder_type: cnn` builds vita_amd.decoders.CNNActionDecoder this way."""
         super().__init__()
         self.config = config
         self.stats = stats
@@ -297,11 +345,8 @@ class VitaPolicy(nn.Module):
             raise ValueError(f"Unsupported recon_loss_type: {ae.recon_loss_type}. Use 'l1' or 'l2'.")   # :71
         self.enc_contrastive_weight = pol.vita.enc_contrastive_weight
         self.flow_contrastive_weight = pol.vita.flow_contrastive_weight
-        if self.use_action_vae and net.decoder_type == "cnn":
-            raise NotImplementedError("action_ae.use_variational with decoder_type 'cnn' (CNNActionDecoder, action_vae.py:232-298) "
-                                      "is outside this build's fused training path; decoder_type 'simple' is built")
         self.obs_encoder = nn.Linear(self.obs_dim, self.latent_dim)                                      # :77
-        self.external_encoder = action_encoder is not None or (net.encoder_type == "transformer" and not self.use_action_vae)
+        self.external_encoder = action_encoder is not None or net.encoder_type == "transformer"
         if action_encoder is not None:
             self.action_encoder = action_encoder
         elif self.external_encoder:                                                                      # action_ae.py:354-364
@@ -309,15 +354,23 @@ class VitaPolicy(nn.Module):
             self.action_encoder = TransformerActionEncoder(enc_hidden_dim=net.enc_hidden_dim, latent_dim=self.latent_dim,
                                                            num_heads=net.num_heads, pred_horizon=self.pred_horizon,
                                                            action_dim=self.action_dim, num_layers=net.num_layers,
-                                                           mlp_ratio=net.get("mlp_ratio", 4.0), dropout=net.get("dropout", 0.0))
+                                                           mlp_ratio=net.get("mlp_ratio", 4.0), dropout=net.get("dropout", 0.0),
+                                                           variational=bool(self.use_action_vae))             # action_vae.py:408-418
         else:
             self.action_encoder = make_action_encoder(net.encoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
                                                       net.enc_hidden_dim, net.num_layers, bool(self.use_action_vae))   # :101-110
-        if self.external_encoder and self.use_action_vae:
-            raise NotImplementedError("an external action encoder with action_ae.use_variational is not built (the module would "
-                                      "have to sample and add its own KL term)")
-        self.action_decoder = make_action_decoder(net.decoder_type, self.pred_horizon, self.action_dim, self.latent_dim,
-                                                  net.dec_hidden_dim, net.num_layers)
+        cnn_decoder = bool(self.use_action_vae) and net.decoder_type == "cnn"                            # action_vae.py:422-429
+        self.external_decoder = action_decoder is not None or cnn_decoder
+        if action_decoder is not None:
+            self.action_decoder = action_decoder
+        elif cnn_decoder:
+            from .decoders import CNNActionDecoder
+            self.action_decoder = CNNActionDecoder(pred_horizon=self.pred_horizon, action_dim=self.action_dim, latent_dim=self.latent_dim,
+                                                   hidden_dim=net.get("dec_hidden_dim", 512), num_layers=net.get("num_layers", 4))
+        else:
+            # the variational factory takes every other decoder_type as 'simple' (action_vae.py:430-438); the plain one raises (action_ae.py:385-386)
+            self.action_decoder = make_action_decoder("simple" if self.use_action_vae else net.decoder_type, self.pred_horizon,
+                                                      self.action_dim, self.latent_dim, net.dec_hidden_dim, net.num_layers)
         fn = pol.flow_net
         if fn.name not in FLOW_NET_NAMES + (MEAN_FLOW_NET_NAME,):
             raise ValueError(f"Unsupported flow_net: {fn.name}")                                         # :89
@@ -329,8 +382,9 @@ class VitaPolicy(nn.Module):
         self._mf_cfg = None
         if self.mean_flow != isinstance(self.FM, MeanFlowMatcher):
             raise ValueError("flow_net 'simple_mean_flow_net' goes with the 'mean' / 'improved_mean' flow matchers, and only with them")
-        if self.mean_flow and self.external_encoder:
-            raise NotImplementedError("an external / transformer action encoder is built for the default (torchcfm) matchers' fused step only")
+        if self.mean_flow and (self.external_encoder or self.external_decoder):
+            raise NotImplementedError("an external action encoder / decoder (transformer, cnn) is built for the default (torchcfm) "
+                                      "matchers' fused step only")
         if self.mean_flow:
             self.flow_net = make_mean_flow_net(self.latent_dim, fn.hidden_dim, fn.num_layers, fn.mlp_ratio)
         else:
@@ -341,6 +395,8 @@ class VitaPolicy(nn.Module):
         self.gemm_dtype = str(pol.get("gemm_dtype", "f32"))
         if self.gemm_dtype not in ("f32", "bf16", "bf16_all"):
             raise ValueError(f"policy.gemm_dtype must be 'f32', 'bf16' or 'bf16_all', got {self.gemm_dtype!r}")
+        if self.external_decoder and self.gemm_dtype != "f32":
+            raise NotImplementedError("an external action decoder goes with policy.gemm_dtype 'f32'")
         self._loss_cfg = ops.loss_config(num_steps=self.num_sampling_steps, recon=ae.recon_loss_type,
                                          decode_flow_latents=bool(pol.vita.decode_flow_latents),
                                          consistency_weight=float(pol.vita.consistency_weight),
@@ -390,7 +446,7 @@ class VitaPolicy(nn.Module):
         for prefixes in self.BUCKET_PREFIXES:
             group = []
             for k, p in named.items():
-                if self.external_encoder and k.startswith("action_encoder."):
+                if (self.external_encoder and k.startswith("action_encoder.")) or (self.external_decoder and k.startswith("action_decoder.")):
                     continue        # a torch module beside the fused path: its gradients come through autograd
                 if k.startswith(prefixes) and p.requires_grad:
                     group.append((k, p))
@@ -496,10 +552,18 @@ class VitaPolicy(nn.Module):
             if self.mean_flow:
                 c = (self._key(), ops.MeanFlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev), None)
             else:
-                c = (self._key(), ops.FlowNetHandle(sd, dev), ops.DecoderHandle(sd, dev),
-                     ops.PolicyHandle(sd, dev, self.pred_horizon, external_encoder_action_dim=self.action_dim if self.external_encoder else None))
+                c = (self._key(), ops.FlowNetHandle(sd, dev), None if self.external_decoder else ops.DecoderHandle(sd, dev),
+                     ops.PolicyHandle(sd, dev, self.pred_horizon, **self._external_kw()))
             self._cache["infer"] = c
         return c[1], c[2], c[3]
+
+    def _external_kw(self) -> dict:
+        kw = {}
+        if self.external_encoder:
+            kw["external_encoder_action_dim"] = self.action_dim
+        if self.external_decoder:
+            kw["external_decoder_action_dim"] = self.action_dim
+        return kw
 
     def _train_handles(self, stage: bool = False):
         """(weights, gradient descriptor, {name: gradient tensor}).  stage=False: the gradient tensors ARE the parameters'
@@ -524,7 +588,7 @@ class VitaPolicy(nn.Module):
                 gsd = {k: torch.zeros_like(p.data) for k, p in named}
             dev = self.obs_encoder.weight.device
             handle = ops.MeanFlowPolicyHandle if self.mean_flow else ops.PolicyHandle
-            kw = {"external_encoder_action_dim": self.action_dim} if self.external_encoder else {}
+            kw = self._external_kw()
             c = (self._key(), handle(sd, dev, self.pred_horizon, strict=True, **kw), handle(gsd, dev, self.pred_horizon, strict=True, **kw), gsd)
             self._cache[slot] = c
         return c[1], c[2], c[3]
@@ -563,7 +627,7 @@ class VitaPolicy(nn.Module):
             _, _, pw = self._infer_handles()
             z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
             z1 = enc_latents.detach() if enc_latents is not None else ops.action_encoder_forward(pw, actions)
-            if self.use_action_vae:     # (B, 2D) rows [mean | logvar]; the sample feeds only the host-side OT plan here
+            if self.use_action_vae and enc_latents is None:     # (B, 2D) rows [mean | logvar]; the sample feeds only the host-side OT plan here
                 mean, logvar = z1[:, :self.latent_dim], z1[:, self.latent_dim:]
                 z1 = mean if enc_noise is None else mean + torch.exp(0.5 * logvar) * enc_noise
             from .flow import exact_ot_pairing
@@ -581,9 +645,9 @@ class VitaPolicy(nn.Module):
         if self.inference_only:
             raise NotImplementedError(f"training with flow matcher '{self.config.policy.flow_matcher.name}' is not built "
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
-        if self.external_encoder:
-            raise NotImplementedError("the native trainer (flat buffers, fused optimizer) has no external / transformer action encoder: "
-                                      "train it through compute_loss(...).backward() with a torch optimizer (the drop-in path)")
+        if self.external_encoder or self.external_decoder:
+            raise NotImplementedError("the native trainer (flat buffers, fused optimizer) has no external action encoder / decoder "
+                                      "(transformer, cnn): train it through compute_loss(...).backward() with a torch optimizer (the drop-in path)")
         obs_features = self.observer(batch)
         actions = batch[self.config.task.action_key]
         pw, gw, gsd = self._train_handles()
@@ -618,20 +682,43 @@ class VitaPolicy(nn.Module):
         actions = batch[self.config.task.action_key]
         if self.mean_flow:
             return self._compute_loss_meanflow(obs_features, actions, t, pair_i, enc_noise)
-        enc_latents = None
+        enc_latents, kl_rows = None, None
         if self.external_encoder:       # :118-123 — under no_grad when the encoder is frozen
             with torch.set_grad_enabled(torch.is_grad_enabled() and not self.freeze_action_encoder):
                 enc_latents = self.action_encoder(actions)
+                if self.use_action_vae:     # DiagonalGaussianDistribution(params, deterministic=not training), dists.py:4-35
+                    mean, logvar = torch.chunk(enc_latents, 2, dim=1)
+                    if self.training:
+                        if enc_noise is None:
+                            enc_noise = torch.randn_like(mean)
+                        enc_latents = mean + torch.exp(0.5 * logvar) * enc_noise
+                        kl_rows = 0.5 * torch.sum(torch.pow(mean, 2) + torch.exp(logvar) - 1.0 - logvar, dim=1)
+                    else:
+                        enc_latents, kl_rows = mean, torch.zeros(mean.shape[0], device=mean.device)
+                    enc_latents = enc_latents.contiguous()
         t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
                                                             actions, enc_noise, fm_noise, enc_latents)
-        if torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters()):
+        if self.external_encoder:
+            enc_noise = None        # the posterior's draw was used above; the fused call sees plain latents
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for _, p in self.hot_path_named_parameters())
+        latents = None
+        if with_grad:
             params = [p for _, p in self.hot_path_named_parameters()]
-            loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, enc_latents, *params)
+            if self.external_decoder:
+                loss, losses, latents = _FusedLossExternalDecoder.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise,
+                                                                        enc_latents, *params)
+            else:
+                loss, losses = _FusedLoss.apply(self, obs_features, actions, t, pair_i, pair_j, enc_noise, fm_noise, enc_latents, *params)
         else:
             _, _, pw = self._infer_handles()
-            losses = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise,
-                                      fm_noise=fm_noise, enc_latents=enc_latents.detach() if enc_latents is not None else None)[0]
+            out = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise,
+                                   fm_noise=fm_noise, enc_latents=enc_latents.detach() if enc_latents is not None else None)
+            losses = out[0]
             loss = losses[0]
+            if self.external_decoder:
+                latents = out[-1]
+        if self.external_decoder or kl_rows is not None:    # the terms of modules that run under torch autograd beside the fused call
+            loss, losses = self._external_terms(loss, losses, latents, actions, kl_rows)
         vals = losses.detach().cpu().tolist()
         metrics = {"loss": vals[1], "flow_loss": vals[1]}   # FM.compute_loss's own 'loss' entry is the flow loss (flow_matchers.py:39)
         cfgv = self.config.policy.vita
@@ -650,6 +737,29 @@ class VitaPolicy(nn.Module):
         if self.enc_action_recon_weight > 0 and not fd:
             metrics["enc_action_recon_loss"] = vals[4]
         return loss, metrics
+
+    def _external_terms(self, loss, losses, latents, actions, kl_rows):
+        """The loss terms of modules outside the fused call: an external variational encoder's KL (vita_policy.py:146-150) and an
+        external decoder's reconstruction terms (:174-187) on the latents [pred; z1] the fused forward handed out.  Returns
+        (loss + weighted terms, the losses vector with those entries filled in)."""
+        B = actions.shape[0]
+        recon = F.l1_loss if self.config.policy.action_ae.recon_loss_type == "l1" else F.mse_loss
+        fe, fd = self.freeze_action_encoder, self.freeze_action_decoder
+        terms = {}
+        if not (fe and fd) and kl_rows is not None and not fe and self.action_kl_weight > 0:         # :142-150
+            terms[L.LOSS_NAMES.index("action_kl_loss")] = (self.action_kl_weight, kl_rows.mean())
+        if not (fe and fd) and self.external_decoder:                                                # :142-143
+            if self.config.policy.vita.decode_flow_latents and not fe and not fd and self.flow_action_recon_weight > 0:
+                terms[L.LOSS_NAMES.index("flow_action_recon_loss")] = (self.flow_action_recon_weight, recon(self.action_decoder(latents[:B]), actions))
+            if self.enc_action_recon_weight > 0 and not fd:
+                terms[L.LOSS_NAMES.index("enc_action_recon_loss")] = (self.enc_action_recon_weight, recon(self.action_decoder(latents[B:]), actions))
+        if terms:
+            losses = losses.clone()
+            for i, (w, v) in terms.items():
+                loss = loss + w * v
+                losses[i] = v.detach()
+            losses[0] = loss.detach()
+        return loss, losses
 
     def _compute_loss_meanflow(self, obs_features, actions, t=None, r=None, enc_noise=None):
         """compute_loss for flow_matcher.name = 'mean' (mean_flow_matcher.py:109-199 inside vita_policy.py:112-189); metric keys
@@ -702,9 +812,12 @@ class VitaPolicy(nn.Module):
         """vita_policy.py:191-208: observer features -> obs_encoder -> K Euler steps -> decoder, one C-ABI call."""
         obs_features = self.observer(batch)
         fw, dw, _ = self._infer_handles()
-        if self.inference_only or self.mean_flow:   # mean / improved_mean / consistency: obs_encoder -> FM.sample -> decoder, three C-ABI calls
+        if self.inference_only or self.mean_flow or self.external_decoder:
+            # mean / improved_mean / consistency, or a decoder that is a torch module: obs_encoder -> FM.sample -> decoder
             z0 = ops.linear(obs_features, self.obs_encoder.weight.data, self.obs_encoder.bias.data)
             z = self.FM.sample(fw, shape=tuple(z0.shape), device=z0.device, start=z0, num_steps=self.num_sampling_steps)
+            if self.external_decoder:
+                return self.action_decoder(z).reshape(-1, self.pred_horizon, self.action_dim)
             return ops.decoder_forward(dw, z).view(-1, self.pred_horizon, self.action_dim)
         if self.gemm_dtype != "f32":
             out = ops.generate_actions_bf16(self.obs_encoder.bias.data, fw, dw, self._bf16_weights(), obs_features,
