@@ -232,6 +232,9 @@ static int ode_sample(const vita_flownet_weights* w, const float* x0, int64_t ld
     }
     if (f.sync)     // per-launch path on a workspace that could hold a persistent solve's state: its status word reads "completed"
         VITA_CHECK_HIP(hipMemsetAsync(reinterpret_cast<char*>(f.sync) + ode_persistent_status_offset(), 0, 128, s));
+    // few-row batches: fc2's reduction (K = FF) is split over workgroups; the kernels finish it themselves (vita_splitk_fused.h)
+    static const bool no_fused = getenv("VITA_NO_FUSED_SPLITK") != nullptr && atoi(getenv("VITA_NO_FUSED_SPLITK")) != 0;
+    if (B <= 512 && !no_fused && !tl_ws_symbol) VITA_REQUIRE(sk.enable_fused(s) == 0, "vita_ode_sample_f32: could not zero the split-K counters");
     const float* src = x0;
     int64_t lds = ldx0;
     for (int k = 0; k < K; ++k) {

@@ -53,6 +53,7 @@ struct SplitK {
     int k_per_split = 0;      // multiple of 128 (so of every kernel's BK)
     float* partial = nullptr;
     int64_t ld_partial = 0;
+    int* counters = nullptr;   // kernels that can: the last split to arrive at counters[tile] reduces and applies the epilogue (no second pass)
 };
 
 inline bool epi_aligned(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; }

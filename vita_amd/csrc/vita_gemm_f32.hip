@@ -461,10 +461,16 @@ static int run_small(const vita_linear_args& a, hipStream_t stream) {
             sk.partial = static_cast<float*>(a.splitk_ws);
             sk.ld_partial = ldp;
             if (sk.splits < 2) sk.splits = 1;
+            // the orchestrator's scratch with zeroed tile counters: the kernel finishes the reduction itself
+            const SplitkScratch& sc = splitk_scratch();
+            const long tiles = (long)((a.M + 31) / 32) * ((a.N + 31) / 32);
+            if (sk.splits > 1 && sc.counters != nullptr && a.splitk_ws == sc.ptr && tiles <= kSplitkCounters &&
+                (size_t)sk.splits * a.M * ldp * sizeof(float) <= sc.bytes)
+                sk.counters = sc.counters;
         }
     }
     VITA_TRY_RC(gemm_f32_small(a, stream, sk.splits > 1 ? &sk : nullptr));
-    if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
+    if (sk.splits > 1 && sk.counters == nullptr) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
     return VITA_OK;
 }
 static bool small_ws_ok(const vita_linear_args& a) {

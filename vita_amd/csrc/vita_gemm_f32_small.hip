@@ -13,6 +13,7 @@
 #include <stdlib.h>
 
 #include "vita_gemm_dma_tile.h"
+#include "vita_splitk_fused.h"
 
 namespace vita {
 
@@ -23,6 +24,7 @@ struct SmallParams {
     int tiles_n;
     int kw;                  // k elements per wave (multiple of 8)
     int sk_splits, sk_k;     // grid-level split-K (k elements per split, multiple of 8)
+    int* sk_counters;        // non-null: one zeroed counter per output tile; the last split to arrive finishes the tile (vita_splitk_fused.h)
     EpiParams epi;
 };
 
@@ -61,7 +63,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
     const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
     const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
     const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
-    const bool fast = tid < 256 && e.partial == nullptr && e.vec && row < e.M && col + 3 < e.N;
+    const bool fused = e.partial != nullptr && p.sk_counters != nullptr;
+    const bool fast = tid < 256 && (e.partial == nullptr || fused) && e.vec && row < e.M && col + 3 < e.N;
     f32x4 pbias = {0.f, 0.f, 0.f, 0.f}, pzin = pbias, prs = pbias, pg = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
     if (fast) {
         if (e.bias) pbias = *reinterpret_cast<const f32x4*>(e.bias + col);
@@ -103,20 +106,35 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * SM_TS + fr] = acc[r];
     __syncthreads();
-    if (tid >= 256) return;
-    f32x4 s = *reinterpret_cast<const f32x4*>(red + lr * SM_TS + lc);
+    if (tid >= 256 && !fused) return;
+    const bool inb = tid < 256 && row < e.M && col < e.N;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (tid < 256) {
+        s = *reinterpret_cast<const f32x4*>(red + lr * SM_TS + lc);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * (32 * SM_TS) + lr * SM_TS + lc);
+        for (int w = 1; w < NW; ++w) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * (32 * SM_TS) + lr * SM_TS + lc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += t[k];
+            for (int k = 0; k < 4; ++k) s[k] += t[k];
+        }
     }
-    if (row >= e.M || col >= e.N) return;
-    if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
-        float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
-        if (col + 3 < e.N) *reinterpret_cast<f32x4*>(dst) = s;
-        else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
-        return;
+    if (fused) {                    // grid-level split-K finished here by the last workgroup of the tile
+        __shared__ int last_flag;
+        const unsigned split_bytes = (unsigned)e.M * (unsigned)e.ld_partial * 4u;
+        const __amdgpu_buffer_rsrc_t rp = skf_rsrc(e.partial, split_bytes * (unsigned)p.sk_splits);
+        const unsigned poff = ((unsigned)row * (unsigned)e.ld_partial + (unsigned)col) * 4u;
+        if (inb) skf_store16(rp, (unsigned)split * split_bytes + poff, s);      // ld_partial % 4 == 0: the padded row takes the float4
+        if (!skf_arrive_last(p.sk_counters + bid, p.sk_splits, &last_flag)) return;
+        if (!inb) return;
+        s = skf_sum(rp, poff, split_bytes, p.sk_splits);
+    } else {
+        if (!inb) return;
+        if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
+            float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
+            if (col + 3 < e.N) *reinterpret_cast<f32x4*>(dst) = s;
+            else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
+            return;
+        }
     }
     if (fast) {
         const f32x4 bias = pbias, zin = pzin, g = pg, rs = prs;
@@ -183,7 +201,8 @@ __global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) 
     const bool gate_vec = (e.gate != nullptr) && (e.ld_gate == 0);
     const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
     const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
-    const bool fast = e.partial == nullptr && e.vec && row < e.M && col + 3 < e.N;
+    const bool fused = e.partial != nullptr && p.sk_counters != nullptr;
+    const bool fast = (e.partial == nullptr || fused) && e.vec && row < e.M && col + 3 < e.N;
     f32x4 pbias = {0.f, 0.f, 0.f, 0.f}, pzin = pbias, prs = pbias, pg = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
     if (fast) {
         if (e.bias) pbias = *reinterpret_cast<const f32x4*>(e.bias + col);
@@ -277,12 +296,24 @@ __global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) 
 #pragma unroll
         for (int k = 0; k < 4; ++k) s[k] += t[k];
     }
-    if (row >= e.M || col >= e.N) return;
-    if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
-        float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
-        if (col + 3 < e.N) *reinterpret_cast<f32x4*>(dst) = s;
-        else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
-        return;
+    const bool inb = row < e.M && col < e.N;
+    if (fused) {                    // grid-level split-K finished here by the last workgroup of the tile
+        __shared__ int last_flag;
+        const unsigned split_bytes = (unsigned)e.M * (unsigned)e.ld_partial * 4u;
+        const __amdgpu_buffer_rsrc_t rp = skf_rsrc(e.partial, split_bytes * (unsigned)p.sk_splits);
+        const unsigned poff = ((unsigned)row * (unsigned)e.ld_partial + (unsigned)col) * 4u;
+        if (inb) skf_store16(rp, (unsigned)split * split_bytes + poff, s);      // ld_partial % 4 == 0: the padded row takes the float4
+        if (!skf_arrive_last(p.sk_counters + bid, p.sk_splits, &last_flag)) return;
+        if (!inb) return;
+        s = skf_sum(rp, poff, split_bytes, p.sk_splits);
+    } else {
+        if (!inb) return;
+        if (e.partial != nullptr) {     // grid-level split-K: raw sums (ld_partial % 4 == 0, 16-byte aligned buffer)
+            float* dst = e.partial + ((int64_t)split * e.M + row) * e.ld_partial + col;
+            if (col + 3 < e.N) *reinterpret_cast<f32x4*>(dst) = s;
+            else for (int k = 0; k < 4 && col + k < e.N; ++k) dst[k] = s[k];
+            return;
+        }
     }
     if (fast) {
         const f32x4 bias = pbias, zin = pzin, g = pg, rs = prs;
@@ -342,6 +373,7 @@ int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* 
     int kspan = a.K;
     if (sk && sk->splits > 1) {
         p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; e.partial = sk->partial; e.ld_partial = sk->ld_partial;
+        p.sk_counters = sk->counters;
         kspan = sk->k_per_split;
     }
     const int nw = kspan <= 512 ? 4 : 8;

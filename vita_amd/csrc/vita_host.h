@@ -73,15 +73,28 @@ struct Carver {
 
 // Split-K scratch of the running orchestrator (thread-local: entry points are re-entrant per stream/thread).  Every
 // vita_linear_args built by lin()/dgrad()/wgrad() inside the scope carries it.
-struct SplitkScratch { void* ptr = nullptr; size_t bytes = 0; };
+// counters: NULL, or kSplitkCounters zeroed ints at the tail of the scratch for the kernels that finish a split-K reduction
+// themselves (vita_splitk_fused.h); zeroed by enable_fused on the scope's stream, kept at zero by the kernels.
+struct SplitkScratch { void* ptr = nullptr; size_t bytes = 0; int* counters = nullptr; };
+constexpr int kSplitkCounters = 2048;
 inline SplitkScratch& splitk_scratch() {
     static thread_local SplitkScratch s;
     return s;
 }
 struct SplitkScope {
     SplitkScratch saved;
-    SplitkScope(void* p, size_t n) : saved(splitk_scratch()) { splitk_scratch().ptr = p; splitk_scratch().bytes = n; }
+    SplitkScope(void* p, size_t n) : saved(splitk_scratch()) { splitk_scratch().ptr = p; splitk_scratch().bytes = n; splitk_scratch().counters = nullptr; }
     ~SplitkScope() { splitk_scratch() = saved; }
+    // one memset per entry-point call instead of one reduce launch per split GEMM; every GEMM of the scope must run on `st`
+    int enable_fused(hipStream_t st) {
+        SplitkScratch& s = splitk_scratch();
+        const size_t tail = (size_t)kSplitkCounters * sizeof(int);
+        if (s.ptr == nullptr || s.bytes < (size_t(1) << 20)) return 0;
+        s.bytes -= tail;
+        s.counters = reinterpret_cast<int*>(static_cast<char*>(s.ptr) + s.bytes);
+        if (hipMemsetAsync(s.counters, 0, tail, st) != hipSuccess) { s.counters = nullptr; return -1; }
+        return 0;
+    }
 };
 // bf16-operand training GEMMs (vita_loss_config.gemm_bf16): inside the scope gemm_f32() stages both operands of an
 // eligible call as k-contiguous bf16 rows in `ptr` (stream-ordered reuse) and runs the bf16 LDS-DMA kernel; mode 1 only

@@ -17,6 +17,8 @@
 //     shift) gradients of the flow-matching evaluation land directly in the time path's gradient
 //     table, those of Euler step k are column-summed into row B + k.
 //   * Gradients are written, not accumulated: each weight's gradient is produced by exactly one GEMM.
+#include <stdlib.h>
+
 #include "vita_host.h"
 
 namespace vita {
@@ -767,6 +769,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     float* z1 = s.ZZ + (size_t)B * D;
     FlowCtx fc{&w->flow, s.flow, B, K, 1 + K, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
+    // few-row GEMMs with a split reduction finish it in the kernel (vita_splitk_fused.h): one memset here instead of ~50 reduce launches
+    static const bool no_fused = getenv("VITA_NO_FUSED_SPLITK") != nullptr && atoi(getenv("VITA_NO_FUSED_SPLITK")) != 0;
+    if (!no_fused) VITA_REQUIRE(skscope.enable_fused(st) == 0, "%s: could not zero the split-K counters", who);
     Bf16Scope bfscope(s.stage, s.stage_bytes, cfg->gemm_bf16);
     WtScope wtscope;
     if (s.wt) VITA_TRY(stage_wt(wtscope, s.wt, &w->flow, nullptr, w->dec, w->enc, st));
