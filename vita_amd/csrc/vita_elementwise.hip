@@ -194,7 +194,9 @@ __global__ __launch_bounds__(EW_THREADS) void norm_kernel(const float* __restric
 constexpr int LN_MAXC = 8;
 // NC = float4 chunks per lane (H <= 256*NC), ROWS = rows per wave: all of a wave's loads are issued before the first
 // reduction so several rows are in flight per wave (at one row per wave the kernel ran at 2.1 TB/s, latency-bound).
-template <int NC, int ROWS>
+// SV: the modulation vectors are shared by all rows (ld = 0) and 16-byte loadable: held once per wave (ROWS x fewer registers
+// and L1 requests for them)
+template <int NC, int ROWS, bool SV = false>
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
                                                      int M, int H, float eps, int mod, const float* __restrict__ mul, int64_t ld_mul,
                                                      const float* __restrict__ add, int64_t ld_add, int vec, uint16_t* __restrict__ ybf,
@@ -223,10 +225,13 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
     }
     // the modulation vectors are requested together with the rows (not after the two reductions): one memory round trip
     // instead of two on the critical path of a latency-bound kernel
-    f32x4 m4[ROWS][NC], a4[ROWS][NC];
+    // (vectors shared by all rows — the sampler's per-step modulation, ld = 0 — are loaded once per wave, not once per row:
+    // at 4 rows per wave the repeated loads were two thirds of the kernel's L1 requests)
+    constexpr int VR = SV ? 1 : ROWS;
+    f32x4 m4[VR][NC], a4[VR][NC];
     if (vec) {
 #pragma unroll
-        for (int r = 0; r < ROWS; ++r) {
+        for (int r = 0; r < VR; ++r) {
             const int row = min(row0 + r, M - 1);
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -278,8 +283,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const float n = (v[r][c][j] - mu[r]) * rstd[r];
-                        const float m = mod ? (m4[r][c][j] + 1.0f) : m4[r][c][j];
-                        o[j] = n * m + a4[r][c][j];
+                        const float m = mod ? (m4[SV ? 0 : r][c][j] + 1.0f) : m4[SV ? 0 : r][c][j];
+                        o[j] = n * m + a4[SV ? 0 : r][c][j];
                     }
                     if (y) *reinterpret_cast<f32x4*>(yr + k) = o;
                     if (ybf) {   // bf16 copy: the next bf16 GEMM's A operand
@@ -318,9 +323,16 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
     const int vec = (H % 4 == 0) && (ldx % 4 == 0) && (y == nullptr || (ldy % 4 == 0 && al16(y))) && al16(x) && al16(mul) && al16(add) &&
                     (ld_mul % 4 == 0) && (ld_add % 4 == 0);
     const int md = mode == VITA_PRO_LN_MOD ? 1 : 0;
+    const bool sv = vec && ld_mul == 0 && ld_add == 0;
 #define VITA_LN(NC, ROWS)                                                                                                       \
-    hipLaunchKernelGGL((ln_mod_kernel<NC, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps, md, \
-                       mul, ld_mul, add, ld_add, vec, ybf, ld_ybf)
+    do {                                                                                                                        \
+        if (sv && ROWS > 1)                                                                                                     \
+            hipLaunchKernelGGL((ln_mod_kernel<NC, ROWS, true>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, s, x, ldx, y, ldy, M, H, \
+                               eps, md, mul, ld_mul, add, ld_add, vec, ybf, ld_ybf);                                             \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((ln_mod_kernel<NC, ROWS>), dim3((M + 4 * ROWS - 1) / (4 * ROWS)), dim3(256), 0, s, x, ldx, y, ldy, M, H, eps,  \
+                               md, mul, ld_mul, add, ld_add, vec, ybf, ld_ybf);                                                  \
+    } while (0)
 #ifndef VITA_LN_ROWS
 #define VITA_LN_ROWS 4
 #endif
