@@ -45,6 +45,7 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         run()
     else:
-        for env in ({}, {"VITA_NO_FUSED_SPLITK": "1"}, {}, {"VITA_NO_FUSED_SPLITK": "1"}):
+        variants = ({}, {"VITA_NO_FUSED_SPLITK": "1"}, {}, {"VITA_NO_FUSED_SPLITK": "1"})
+        for env in variants:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
             print(r.stdout.strip().splitlines()[-1] if r.stdout.strip() else r.stderr[-2000:])

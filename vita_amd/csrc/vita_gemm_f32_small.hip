@@ -172,11 +172,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
 // the fragment reads are conflict-free), waits for its own DMAs block by block (no workgroup barrier: the region is the
 // wave's own) and reads the fragments back with ds_read_b128.  Same MFMAs in the same order on the same values as the
 // kernel above: the same bits.  A column operand (BCOL) keeps its four coalesced dword loads per chunk.
-template <bool BCOL>
-__global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) {
-    constexpr int NW = 4, KB = 32, NBLK = 4;                  // 32-k blocks per wave: kw <= 128
+// NW = 8 (k span 257..512: 64 k per wave, two blocks) halves the MFMA chain behind the DMA latency of a one-round launch.
+template <bool BCOL, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_f32_small_lds_kernel(SmallParams p) {
+    constexpr int KB = 32, NBLK = 16 / NW;                    // 32-k blocks per wave: kw <= 128 (NW = 4) or 64 (NW = 8)
+    constexpr int WREG = 2 * NBLK * 32 * KB;                  // floats of a wave's region
     extern __shared__ __attribute__((aligned(16))) float stage[];     // [NW][A: NBLK x 32 x 32 | B: NBLK x 32 x 32]
-    __shared__ __attribute__((aligned(16))) float red[NW * 32 * SM_TS];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int fr = lane & 31, fh = lane >> 5;
@@ -190,11 +191,12 @@ __global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) 
     const int k0 = kbase + wave * p.kw;
     const int k1 = min(Kend, k0 + p.kw);
     const int nch = k1 > k0 ? (k1 - k0 + 7) / 8 : 0;
-    float* sa = stage + wave * (2 * NBLK * 32 * KB);
+    float* sa = stage + wave * WREG;
     float* sb = sa + NBLK * 32 * KB;
 
     // epilogue operands of this thread's output float4, requested first (they return first: the DMA waits below count DMAs only)
-    const int lr = tid >> 3, lc = (tid & 7) * 4;
+    const bool epi_thread = tid < 256;
+    const int lr = (tid & 255) >> 3, lc = (tid & 7) * 4;
     const int row = m0 + lr, col = n0 + lc;
     const EpiParams& e = p.epi;
     const bool bwd = e.act_grad_z != nullptr;
@@ -202,7 +204,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) 
     const bool gate_mat = (e.gate != nullptr) && (e.ld_gate != 0);
     const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
     const bool fused = e.partial != nullptr && p.sk_counters != nullptr;
-    const bool fast = (e.partial == nullptr || fused) && e.vec && row < e.M && col + 3 < e.N;
+    const bool fast = epi_thread && (e.partial == nullptr || fused) && e.vec && row < e.M && col + 3 < e.N;
     f32x4 pbias = {0.f, 0.f, 0.f, 0.f}, pzin = pbias, prs = pbias, pg = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar};
     if (fast) {
         if (e.bias) pbias = *reinterpret_cast<const f32x4*>(e.bias + col);
@@ -211,6 +213,7 @@ __global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) 
         else if (gate_mat) pg = *reinterpret_cast<const f32x4*>(e.gate + (int64_t)row * e.ld_gate + col);
         if (e.resid) prs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
     }
+    // (NW = 8: waves 4..7 issue no epilogue loads, so every wave's DMA counts below start from the same zero or are only ahead)
 
     // ---- DMA sources: lane l of the instruction for rows 8 j .. 8 j + 7 writes row 8 j + l / 8, chunk position l % 8,
     //      so it fetches chunk (l % 8) ^ swz(row) of that row's 128-byte piece
@@ -278,25 +281,35 @@ __global__ __launch_bounds__(256) void gemm_f32_small_lds_kernel(SmallParams p) 
                 }
             }
         };
-        // the wave's DMAs complete in order: block kb is there once at most 8 * (3 - kb) of them are still out
-        wait_vmcnt<24>(); block(0);
-        wait_vmcnt<16>(); block(1);
-        wait_vmcnt<8>();  block(2);
-        wait_vmcnt<0>();  block(3);
+        // the wave's DMAs complete in order: block kb is there once at most 8 * (NBLK - 1 - kb) of them are still out
+        if constexpr (NBLK == 4) {
+            wait_vmcnt<24>(); block(0);
+            wait_vmcnt<16>(); block(1);
+            wait_vmcnt<8>();  block(2);
+            wait_vmcnt<0>();  block(3);
+        } else {
+            wait_vmcnt<8>();  block(0);
+            wait_vmcnt<0>();  block(1);
+        }
     }
 
-    float* mine = red + wave * (32 * SM_TS);
+    // the wave's partial tile goes into its own (now consumed) staging region; the tile is summed in wave order
+    float* mine = sa;
 #pragma unroll
     for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * fh) * SM_TS + fr] = acc[r];
     __syncthreads();
-    f32x4 s = *reinterpret_cast<const f32x4*>(red + lr * SM_TS + lc);
+    if (!epi_thread && !fused) return;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (epi_thread) {
+        s = *reinterpret_cast<const f32x4*>(stage + lr * SM_TS + lc);
 #pragma unroll
-    for (int w = 1; w < NW; ++w) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(red + w * (32 * SM_TS) + lr * SM_TS + lc);
+        for (int w = 1; w < NW; ++w) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(stage + w * WREG + lr * SM_TS + lc);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) s[k] += t[k];
+            for (int k = 0; k < 4; ++k) s[k] += t[k];
+        }
     }
-    const bool inb = row < e.M && col < e.N;
+    const bool inb = epi_thread && row < e.M && col < e.N;
     if (fused) {                    // grid-level split-K finished here by the last workgroup of the tile
         __shared__ int last_flag;
         const unsigned split_bytes = (unsigned)e.M * (unsigned)e.ld_partial * 4u;
@@ -376,14 +389,22 @@ int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* 
         p.sk_counters = sk->counters;
         kspan = sk->k_per_split;
     }
-    const int nw = kspan <= 512 ? 4 : 8;
+#ifndef VITA_SMALL_NW8_MIN_K
+#define VITA_SMALL_NW8_MIN_K 257     // k span from which 8 waves split the reduction (64 k each at 512)
+#endif
+    const int nw = kspan < VITA_SMALL_NW8_MIN_K ? 4 : 8;     // 16 waves of 32 k each: measured slower (B = 128 step 2.98 -> 3.00 ms)
     p.kw = ((kspan + nw - 1) / nw + 7) & ~7;
     const unsigned grid = (unsigned)(p.tiles_n * ((a.M + 31) / 32) * (p.sk_splits > 1 ? p.sk_splits : 1));
     static const bool no_lds = getenv("VITA_SMALL_NO_LDS") != nullptr && atoi(getenv("VITA_SMALL_NO_LDS")) != 0;
-    if (nw == 4 && p.kw <= 128 && !no_lds) {      // operands through LDS (coalesced DMA): the same bits, faster loads
-        constexpr size_t lds = (size_t)4 * 2 * 4 * 32 * 32 * sizeof(float);
-        if (a.b_col) hipLaunchKernelGGL((gemm_f32_small_lds_kernel<true>), dim3(grid), dim3(256), lds, stream, p);
-        else hipLaunchKernelGGL((gemm_f32_small_lds_kernel<false>), dim3(grid), dim3(256), lds, stream, p);
+    if (p.kw <= 512 / nw && !no_lds) {      // operands through LDS (coalesced DMA): the same bits, faster loads
+        constexpr size_t lds = (size_t)4 * 2 * 4 * 32 * 32 * sizeof(float);      // 128 KB either way: NW x NBLK = 16 blocks of 2 x 4 KB
+        if (nw == 4) {
+            if (a.b_col) hipLaunchKernelGGL((gemm_f32_small_lds_kernel<true, 4>), dim3(grid), dim3(256), lds, stream, p);
+            else hipLaunchKernelGGL((gemm_f32_small_lds_kernel<false, 4>), dim3(grid), dim3(256), lds, stream, p);
+        } else {
+            if (a.b_col) hipLaunchKernelGGL((gemm_f32_small_lds_kernel<true, 8>), dim3(grid), dim3(512), lds, stream, p);
+            else hipLaunchKernelGGL((gemm_f32_small_lds_kernel<false, 8>), dim3(grid), dim3(512), lds, stream, p);
+        }
         VITA_CHECK_HIP(hipGetLastError());
         return VITA_OK;
     }
