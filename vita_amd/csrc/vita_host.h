@@ -71,6 +71,21 @@ struct Carver {
     }
 };
 
+// Column sums (bias gradients) of several few-row matrices in one launch; matrices of more than 2048 rows go straight to
+// vita_colsum_f32.  flush() before the results are needed and before a source buffer is overwritten.
+constexpr int kColsumJobs = 16;
+struct ColsumJob { const float* x; int64_t ldx; int M, N; float* out; };
+struct ColsumJobs { ColsumJob j[kColsumJobs]; };
+struct ColsumBatch {
+    ColsumJobs jobs;
+    int n = 0, max_n = 0;
+    float* cs_part;
+    hipStream_t st;
+    ColsumBatch(float* part, hipStream_t s) : cs_part(part), st(s) {}
+    int add(const float* x, int64_t ldx, int M, int N, float* out);
+    int flush();
+};
+
 // Split-K scratch of the running orchestrator (thread-local: entry points are re-entrant per stream/thread).  Every
 // vita_linear_args built by lin()/dgrad()/wgrad() inside the scope carries it.
 // counters: NULL, or kSplitkCounters zeroed ints at the tail of the scratch for the kernels that finish a split-K reduction

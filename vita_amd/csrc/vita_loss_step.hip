@@ -116,20 +116,21 @@ int stack_wgrads(const Stack& s, const Stack& g, const StackWs& w, const float* 
     auto trunk = [&](int i) -> const float* { return (i == s.NL && last_trunk) ? last_trunk : w.A + (size_t)i * tr; };
     auto dA = [&](int i) -> const float* { return (i == s.NL && !s.OUT) ? d_top : w.dA[i]; };
     auto ld_dA = [&](int i) -> int64_t { return (i == s.NL && !s.OUT) ? ld_top : s.TR; };
+    ColsumBatch cb(cs_part, st);      // the bias gradients: one launch for the stack at few rows
     if (s.OUT) {
         VITA_TRY(gemm_f32(wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT), st));
-        VITA_TRY(vita_colsum_f32(d_top, ld_top, M, s.OUT, cs_part, mut(g.out_b), 0, st));
+        VITA_TRY(cb.add(d_top, ld_top, M, s.OUT, mut(g.out_b)));
     }
     for (int i = s.NL - 1; i >= 0; --i) {
         const float* P = w.P + i * ff;
         VITA_TRY(gemm_f32(wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
-        VITA_TRY(vita_colsum_f32(dA(i + 1), ld_dA(i + 1), M, s.TR, cs_part, mut(g.fc2_b[i]), 0, st));
+        VITA_TRY(cb.add(dA(i + 1), ld_dA(i + 1), M, s.TR, mut(g.fc2_b[i])));
         VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
-        VITA_TRY(vita_colsum_f32(P, s.FF, M, s.FF, cs_part, mut(g.fc1_b[i]), 0, st));
+        VITA_TRY(cb.add(P, s.FF, M, s.FF, mut(g.fc1_b[i])));
     }
     VITA_TRY(gemm_f32(wgrad(dA(0), ld_dA(0), x, ldx, mut(g.in_w), s.IN, M, s.IN, s.TR), st));
-    VITA_TRY(vita_colsum_f32(dA(0), ld_dA(0), M, s.TR, cs_part, mut(g.in_b), 0, st));
-    return VITA_OK;
+    VITA_TRY(cb.add(dA(0), ld_dA(0), M, s.TR, mut(g.in_b)));
+    return cb.flush();
 }
 int stack_bwd(const Stack& s, const Stack& g, const StackWs& w, const float* x, int64_t ldx, int M, const float* last_trunk,
               const float* d_top, int64_t ld_top, float* dx, int64_t ld_dx, float* cs_part, hipStream_t st) {
@@ -306,23 +307,24 @@ int time_path_bwd(const FlowCtx& c, const vita_flownet_weights& g, int T, float*
         VITA_CHECK_HIP(hipMemsetAsync(mut(g.te3_b), 0, (size_t)H * 4, c.st));
         return VITA_OK;
     }
+    ColsumBatch cb(cs_part, c.st);    // the bias gradients: one launch at the end (dmod, dte and dhid stay as they are until then)
     for (int l = 0; l < L; ++l) {
         const float* dm = c.f.dmod + (size_t)l * 3 * H;
         vita_linear_args a = dgrad(dm, ldm, w->mod_w[l], H, c.f.dsilu, H, T, H, 3 * H);
         if (l > 0) { a.resid = c.f.dsilu; a.ld_resid = H; }
         VITA_TRY(gemm_f32(a, c.st));
         VITA_TRY(gemm_f32(wgrad(dm, ldm, c.f.silu, H, mut(g.mod_w[l]), H, T, H, 3 * H), c.st));
-        VITA_TRY(vita_colsum_f32(dm, ldm, T, 3 * H, cs_part, mut(g.mod_b[l]), 0, c.st));
+        VITA_TRY(cb.add(dm, ldm, T, 3 * H, mut(g.mod_b[l])));
     }
     VITA_TRY(vita_act_bwd_f32(c.f.tepre, c.f.dsilu, c.f.dte, (int64_t)T * H, VITA_ACT_SILU, c.st));
     VITA_TRY(gemm_f32(wgrad(c.f.dte, H, c.f.hid, 4 * TE, mut(g.te3_w), 4 * TE, T, 4 * TE, H), c.st));
-    VITA_TRY(vita_colsum_f32(c.f.dte, H, T, H, cs_part, mut(g.te3_b), 0, c.st));
     vita_linear_args a = dgrad(c.f.dte, H, w->te3_w, 4 * TE, c.f.dhid, 4 * TE, T, 4 * TE, H);
     a.act = VITA_ACT_MISH; a.act_grad_z = c.f.hidpre; a.ld_act_grad_z = 4 * TE;
     VITA_TRY(gemm_f32(a, c.st));
     VITA_TRY(gemm_f32(wgrad(c.f.dhid, 4 * TE, c.f.sin, TE, mut(g.te1_w), TE, T, TE, 4 * TE), c.st));
-    VITA_TRY(vita_colsum_f32(c.f.dhid, 4 * TE, T, 4 * TE, cs_part, mut(g.te1_b), 0, c.st));
-    return VITA_OK;
+    VITA_TRY(cb.add(c.f.dte, H, T, H, mut(g.te3_b)));
+    VITA_TRY(cb.add(c.f.dhid, 4 * TE, T, 4 * TE, mut(g.te1_b)));
+    return cb.flush();
 }
 
 // SimpleFlowNet.forward (simple_flow_net.py:99-108) up to the final norm for the M rows that start at evaluation e (M = B, or
@@ -407,19 +409,27 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
                       int parts = kWgOuter | kWgLayers) {
     const vita_flownet_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, L = w->L, R = c.E * c.B;
+    // bias-like gradients (column sums of buffers the chains left behind) first, batched: one launch per part at few rows, and
+    // every layer's event below still covers that layer's biases
+    ColsumBatch cb(cs_part, c.st);
+    if (parts & kWgOuter) {
+        VITA_TRY(cb.add(c.f.DV, D, R, D, mut(g.out_b)));
+        VITA_TRY(cb.add(c.f.RN, H, R, H, mut(g.norm_w)));
+        VITA_TRY(cb.add(c.f.DHNF, H, R, H, mut(g.norm_b)));
+        VITA_TRY(cb.add(c.f.DH0, H, R, H, mut(g.in_b)));
+    }
+    for (int l = 0; l < L && (parts & kWgLayers); ++l) {
+        VITA_TRY(cb.add(c.Y2(l, 0), H, R, H, mut(g.fc2_b[l])));
+        VITA_TRY(cb.add(c.U(l, 0), FF, R, FF, mut(g.fc1_b[l])));
+    }
+    VITA_TRY(cb.flush());
     if (parts & kWgOuter) {
         VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
-        VITA_TRY(vita_colsum_f32(c.f.DV, D, R, D, cs_part, mut(g.out_b), 0, c.st));
-        VITA_TRY(vita_colsum_f32(c.f.RN, H, R, H, cs_part, mut(g.norm_w), 0, c.st));
-        VITA_TRY(vita_colsum_f32(c.f.DHNF, H, R, H, cs_part, mut(g.norm_b), 0, c.st));
         VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
-        VITA_TRY(vita_colsum_f32(c.f.DH0, H, R, H, cs_part, mut(g.in_b), 0, c.st));
     }
     for (int l = 0; l < L && (parts & kWgLayers); ++l) {
         VITA_TRY(gemm_f32(wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
-        VITA_TRY(vita_colsum_f32(c.Y2(l, 0), H, R, H, cs_part, mut(g.fc2_b[l]), 0, c.st));
         VITA_TRY(gemm_f32(wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
-        VITA_TRY(vita_colsum_f32(c.U(l, 0), FF, R, FF, cs_part, mut(g.fc1_b[l]), 0, c.st));
         if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
     }
     return VITA_OK;

@@ -3,6 +3,7 @@
 // interpolation backward, and the fused clip + AdamW + EMA update.  All HBM-bound: 16-byte
 // accesses where alignment allows, wave64 shuffle reductions, deterministic two-stage sums.
 #include "vita_common.h"
+#include "vita_host.h"
 
 namespace vita {
 
@@ -344,6 +345,50 @@ __global__ __launch_bounds__(TT) void fm_bwd_kernel(const float* __restrict__ dx
         if (dx0) { if (pi) atomicAdd(&dx0[pi[r] * D + c], g0); else dx0[i] = accumulate ? dx0[i] + g0 : g0; }
         if (dx1) { if (pj) atomicAdd(&dx1[pj[r] * D + c], g1); else dx1[i] = accumulate ? dx1[i] + g1 : g1; }
     }
+}
+
+// the same, up to kColsumJobs matrices in one launch (blockIdx.y = job): the bias gradients of a few-row training step are ~40
+// launches of ~4 us each when taken one by one.  Same summation order per job as colsum_small_kernel: the same bits.
+__global__ __launch_bounds__(1024) void colsum_small_multi_kernel(ColsumJobs jobs) {
+    const ColsumJob& jb = jobs.j[blockIdx.y];
+    const int c = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int col = blockIdx.x * 32 + c;
+    if ((int)blockIdx.x * 32 >= jb.N) return;
+    const float* __restrict__ x = jb.x;
+    const int64_t ldx = jb.ldx;
+    const int M = jb.M;
+    float s0 = 0.f, s1 = 0.f;
+    if (col < jb.N) {
+        int r = rl;
+        for (; r + 32 < M; r += 64) { s0 += x[(int64_t)r * ldx + col]; s1 += x[(int64_t)(r + 32) * ldx + col]; }
+        if (r < M) s0 += x[(int64_t)r * ldx + col];
+    }
+    __shared__ float sh[32][33];
+    sh[rl][c] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && col < jb.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) s += sh[k][c];
+        jb.out[col] = s;
+    }
+}
+
+int ColsumBatch::add(const float* x, int64_t ldx, int M, int N, float* out) {
+    if (M > 2048 || M <= 0) {      // many rows: the two-stage kernels, one call each
+        return vita_colsum_f32(x, ldx, M, N, cs_part, out, 0, st);
+    }
+    ColsumJob& jb = jobs.j[n++];
+    jb.x = x; jb.ldx = ldx; jb.M = M; jb.N = N; jb.out = out;
+    if (N > max_n) max_n = N;
+    return n == kColsumJobs ? flush() : VITA_OK;
+}
+int ColsumBatch::flush() {
+    if (n == 0) return VITA_OK;
+    hipLaunchKernelGGL(colsum_small_multi_kernel, dim3((max_n + 31) / 32, n), dim3(1024), 0, st, jobs);
+    n = 0; max_n = 0;
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
 }
 
 // ---- sum of squares (gradient norm), two-stage ------------------------------------------------------
