@@ -320,7 +320,7 @@ def main():
                "dtype": "f32" if gemm_dtype == "f32" else "bf16 GEMM operands (calls >= 2^31 FLOP), f32 accumulate / master weights / gradients",
                "loss": round(m["loss"], 6), "grad_norm": round(m["grad_norm"], 6),
                "grad_bytes_allreduced_per_step": int(tr.flat_grad.numel() * 4) if tr.reducer.active else 0,
-               "parallelism": f"data-parallel x{w_}, 3 event-driven gradient buckets over RCCL" if w_ > 1 else "single GPU",
+               "parallelism": f"data-parallel x{w_}, {len(tr.plan)} event-driven gradient buckets over RCCL (decoder, encoders, flow net rest, one per layer)" if w_ > 1 else "single GPU",
                "includes": "normalize, fused forward+backward (1 FM eval + K Euler steps + encoder + 2 decodes), grad-norm clip, AdamW, EMA; observer excluded (camera latents are the input)",
                "algorithmic_flops_per_sample_fwd_bwd": f_train}
         if f_train:
@@ -333,8 +333,13 @@ def main():
     if not args.no_train and args.hidden != 512:
         print("bench.py: the training leg uses the default policy dims; skipped for --hidden != 512", file=sys.stderr)
     if not args.no_train and args.hidden == 512:
-        train = train_leg(args.train_batch, "f32", args.train_steps or args.steps, True)
-        if multi:
+        try:
+            train = train_leg(args.train_batch, "f32", args.train_steps or args.steps, True)
+        except Exception as e:          # N > 1: the training leg is a side figure of the line; `value` must survive it
+            if not multi:
+                raise
+            train = {"metric": "train samples/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
+        if multi and train.get("value") is not None:
             # the same step without the collective (each rank alone in a one-rank group): what the all-reduce leaves exposed
             try:
                 solo_groups = [dist.new_group([r]) for r in range(world)]
