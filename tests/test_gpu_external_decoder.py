@@ -113,6 +113,14 @@ def test_external_decoder_equals_the_fused_one():
     assert an.shape == ae.shape and (an - ae).abs().max().item() <= 2e-5
     with pytest.raises(NotImplementedError):
         ext.loss_and_grads(batch, t=t)
+    # two forwards before a backward: the first graph's saved activations are gone, and it says so instead of using the second's
+    ext.train()
+    l1, _ = ext.compute_loss(batch, t=t)
+    l2, _ = ext.compute_loss(batch2, t=t2)
+    from vita_amd._lib import VitaHipError
+    with pytest.raises(VitaHipError):
+        l1.backward()
+    l2.backward()
 
 
 @pytest.mark.parametrize("flags", [dict(freeze_decoder=True), dict(freeze_encoder=True), dict(flow_recon_weight=0.0),

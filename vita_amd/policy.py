@@ -246,6 +246,8 @@ class _FusedLossExternalDecoder(torch.autograd.Function):
         out = ops.compute_loss(pw, policy._loss_cfg, obs_d, actions, t, pair_i=pair_i, pair_j=pair_j, enc_noise=enc_noise, fm_noise=fm_noise,
                                enc_latents=lat_d)
         losses, latents = out[0], out[-1]
+        pw._step_generation = getattr(pw, "_step_generation", 0) + 1      # the saved activations live in the handle's one workspace
+        ctx.generation = pw._step_generation
         ctx.policy, ctx.args = policy, (obs_d, actions, t, pair_i, pair_j, enc_noise, fm_noise, lat_d)
         ctx.need_dobs = obs_features.requires_grad
         ctx.need_dlat = enc_latents is not None and enc_latents.requires_grad
@@ -258,6 +260,10 @@ class _FusedLossExternalDecoder(torch.autograd.Function):
         policy = ctx.policy
         obs_d, actions, t, pair_i, pair_j, enc_noise, fm_noise, lat_d = ctx.args
         pw, gw, gsd = policy._train_handles(stage=True)
+        if getattr(pw, "_step_generation", 0) != ctx.generation:
+            raise L.VitaHipError("compute_loss with an external action decoder: backward() must run before the next compute_loss call of "
+                                 "this policy (the forward's saved activations live in one workspace); accumulate gradients by calling "
+                                 "backward() per micro-batch")
         if gout is None:
             gout = torch.zeros((), dtype=torch.float32, device=obs_d.device)
         scale = torch.where(gout != 0, gout, torch.ones_like(gout))
