@@ -1476,6 +1476,8 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     float* z1 = s.ZZ + (size_t)B * D;
     MfCtx mc{fw, &s, B, E, st};
     SplitkScope skscope(s.sk, kSplitkBytes);
+    static const bool no_fused = getenv("VITA_NO_FUSED_SPLITK") != nullptr && atoi(getenv("VITA_NO_FUSED_SPLITK")) != 0;
+    if (!no_fused) VITA_REQUIRE(skscope.enable_fused(st) == 0, "%s: could not zero the split-K counters", who);   // as in vita_compute_loss_f32
     WtScope wtscope;
     if (s.wt && grads) VITA_TRY(stage_wt(wtscope, s.wt, nullptr, &w->flow, w->dec, w->enc, st));
     const float seeds[6] = {1.0f, cfg->consistency_weight, cfg->flow_recon_weight, cfg->enc_recon_weight, cfg->enc_contrastive_weight,
