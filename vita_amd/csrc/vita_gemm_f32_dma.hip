@@ -182,6 +182,20 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 64, 3>(p, stream);
 #else   // 5: 256x128 tiles when they still give every CU a tile (6 DMA issues per 64 MFMAs per wave instead of 4 per 32)
+    if (fold == nullptr && (sk == nullptr || sk->splits <= 1)) {
+        // (calls with the folded-LayerNorm epilogue keep the rule below: the persistent sampler walks the same tiles and must give
+        // the same bits, tests/test_gpu_persistent.py)
+        // One workgroup per CU at a time: a launch costs ceil(tiles / 256) rounds of its tile's time.  Tile times relative to the
+        // 64-row tile, from the stand-alone kernels at 4096 rows (25.7 / 45 / 83 us per round): 1, 1.8, 3.4.  B = 4096: 256-row tiles
+        // (one round); 2048: 128-row (one round instead of two 64-row ones: sampler 2.99 -> 2.87 ms); 3072: 64-row (three rounds
+        // beat 1.5 -> 2 rounds of 128-row tiles: 3.96 against 4.23 ms).
+        const long nt = (a.N + 127) / 128;
+        auto rounds = [&](int rows) { return (double)((((long)(a.M + rows - 1) / rows) * nt + 255) / 256); };
+        const double c64 = rounds(64) * 1.0, c128 = rounds(128) * 1.8, c256 = rounds(256) * 3.4;
+        if (c256 <= c128 && c256 <= c64 && (long)((a.M + 255) / 256) * nt >= 256) return launch_dma<256, 128, 32, 3>(p, stream);
+        if (c128 < c64) return launch_dma<128, 128, 32, 4>(p, stream);
+        return launch_dma<64, 128, 64, 3, 2, 4>(p, stream);
+    }
     if ((long)((a.M + 255) / 256) * ((a.N + 127) / 128) >= 256 && sk == nullptr) return launch_dma<256, 128, 32, 3>(p, stream);
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     // 64-row tile: 4 k-groups of 2 waves, a wave owns 64x64 outputs over a quarter of each k-tile (fc2 88.9 -> 84 us; 2 groups: 85 us)
