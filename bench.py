@@ -349,6 +349,13 @@ def main():
             except Exception as e:      # a side figure must never cost the scaling line
                 train["exposed_communication_ms_per_step"] = None
                 train["exposed_communication_error"] = repr(e)[:200]
+        if multi and args.train_large_batch > 0:
+            # BASELINE configs[2]: bf16-operand training, data parallel — at a per-GPU batch whose GEMMs take the bf16 kernels (the
+            # default 128 rows per GPU stay fp32: none of their GEMMs reaches the 2^31-FLOP switch)
+            try:
+                train_large_bf16 = train_leg(args.train_large_batch, "bf16", 5, True)
+            except Exception as e:
+                train_large_bf16 = {"metric": "train samples/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1 and args.train_large_batch > 0:
             # side figures at a batch that fills the chip: fp32, and BASELINE configs[2]'s bf16-operand training
             train_large = train_leg(args.train_large_batch, "f32", 5, False)
