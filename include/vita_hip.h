@@ -385,14 +385,15 @@ typedef struct vita_loss_config { /* flare/configs/policy/vita.yaml:15-25,41-46 
                                       forked from and joined back into `stream` with events; grad_ready[0] is then recorded on a side
                                       stream.  Same bits as the single-stream order.  Measured on MI355X: the branches do not overlap
                                       the main chain's small kernels (B=128 step 3.34 -> 3.44 ms), hence off by default */
-    int32_t grad_ready_layers;     /* 1: `grad_ready` holds 3 + L events; entry 3 + l is recorded when the gradients of
-                                      flow_net.layers.l.mlp.{fc1,fc2}.{weight,bias} are final (their stacked weight-gradient GEMMs run
-                                      layer by layer after the input-gradient chains), so a data-parallel caller can start that
-                                      layer's all-reduce while the following layers' weight gradients are still being computed.
-                                      The events are then recorded in the order 0, 2, 1, 3, .., 3 + L - 1 and mean: (0) the decoder's,
-                                      (2) the encoders' and obs_encoder's gradients and d_obs_features, (1) the flow net's OTHER than
-                                      the layers' mlp weights, (3 + l) layer l's — big buckets first, so that only one layer's
-                                      gradients (8 MB at H = 512) become final at the very end of the call.  Same bits either way */
+    int32_t grad_ready_layers;     /* 1: `grad_ready` holds 4 + L events, recorded in the order 0, 3, .., 3 + L - 1, 2, 1, 3 + L as the
+                                      gradients they stand for become final: (0) the decoder's; (3 + l) flow_net.layers.l.mlp.{fc1,fc2}
+                                      .{weight,bias} (the stacked weight-gradient GEMMs run layer by layer after the input-gradient
+                                      chains); (2) the encoders' and obs_encoder's gradients and d_obs_features; (1) the time path's
+                                      (time_embed.*, layers.l.time_modulator.*); (3 + L) the flow net's outer ones (input_proj, norm,
+                                      out_proj).  A data-parallel caller starts each bucket's all-reduce at its event: the sections
+                                      that make the most gradient bytes per unit of compute come first and 2 MB last (at H = 512), so
+                                      that little is left to send when the call's kernels end, whatever the link's speed.  Same
+                                      bits as without it */
     int32_t external_decoder;      /* 1: the action decoder is the caller's own module (any: the reference's CNNActionDecoder /
                                       CNNAttentionActionDecoder, action_vae.py:232-387 ...), vita_compute_loss_f32 with fp32 GEMMs
                                       only.  Of `dec` only D, OUT and in_w are read: in_w of the weights descriptor is a (2B, D)
@@ -431,7 +432,7 @@ enum { VITA_LOSS_TOTAL = 0, VITA_LOSS_FLOW = 1, VITA_LOSS_CONSISTENCY = 2, VITA_
  *   (the ResNet backbone is in the reference's single AdamW group, vita_policy.py:222-229).
  * grad_ready: NULL or 3 hipEvent_t recorded on `stream` when (0) the decoder's, (1) the flow net's, (2) every
  *   gradient is final — the points at which a data-parallel caller starts that bucket's all-reduce; with
- *   cfg->grad_ready_layers, 3 + L events in a different order and with narrower meanings (see vita_loss_config). */
+ *   cfg->grad_ready_layers, 4 + L events in a different order and with narrower meanings (see vita_loss_config). */
 size_t vita_compute_loss_workspace_bytes(const vita_policy_weights* w, const vita_loss_config* cfg, int32_t B);
 int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weights* grads, const vita_loss_config* cfg,
                           const float* obs_features, int64_t ldobs, const float* actions, const float* t,

@@ -235,9 +235,9 @@ def test_bench_self_launches_one_process_per_gpu():
 
 
 def test_reduce_plan_covers_the_flat_buffer_once_in_firing_order():
-    """The data-parallel reduce plan: every hot-path parameter in exactly one segment; decoder first, then the encoders, then
-    the rest of the flow net, then one segment per flow-net layer's fc1 / fc2 gradients (events 3 + l) — the order in which
-    vita_compute_loss_f32 records the events under grad_ready_layers."""
+    """The data-parallel reduce plan: every hot-path parameter in exactly one segment, one contiguous segment per event, in the
+    order in which vita_compute_loss_f32 records the events under grad_ready_layers: decoder (0), one per flow-net layer's fc1 / fc2
+    gradients (3 + l), encoders (2), time path and modulators (1), outer projections and final norm (3 + L)."""
     import torch
     from vita_amd.config import default_config
     from vita_amd.policy import VitaPolicy
@@ -252,10 +252,9 @@ def test_reduce_plan_covers_the_flat_buffer_once_in_firing_order():
     assert bool((cover == 1).all())
     L_ = cfg.policy.flow_net.num_layers
     evs = [ev for _, _, ev in plan]
-    assert evs[0] == 0 and evs[-L_:] == [3 + l for l in range(L_)]
-    mid = evs[1:-L_]
-    n2 = mid.count(2)
-    assert n2 >= 1 and set(mid[:n2]) == {2} and set(mid[n2:]) == {1}
+    assert evs == [0] + [3 + l for l in range(L_)] + [2, 1, 3 + L_]
+    sizes = {ev: hi - lo for lo, hi, ev in plan}
+    assert sizes[3 + L_] == 2 * (H_ := cfg.policy.flow_net.hidden_dim) * cfg.policy.action_ae.net.latent_dim + H_ + cfg.policy.action_ae.net.latent_dim + 2 * H_
     H = cfg.policy.flow_net.hidden_dim
     per_layer = 2 * H * 4 * H + 4 * H + H          # fc1 (4H x H) + fc2 (H x 4H) + their biases
-    assert all(hi - lo == per_layer for lo, hi, ev in plan if ev >= 3)
+    assert all(hi - lo == per_layer for lo, hi, ev in plan if 3 <= ev < 3 + L_)

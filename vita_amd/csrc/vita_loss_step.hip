@@ -990,13 +990,14 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
             VITA_TRY(encoders_bwd(s.cs_side[2], side->s[2]));
             VITA_CHECK_HIP(hipEventRecord(side->join[2], side->s[2]));
         }
-        if (layer_ready) {   // the order of the single-stream branch below: encoders, rest of the flow net, layers
+        if (layer_ready) {   // the order of the single-stream branch below: layers, encoders, time path, outer projections
+            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready, kWgLayers));
             VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[2], 0));
             VITA_TRY(record(2));
-            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, nullptr, kWgOuter));
             VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
             VITA_TRY(record(1));
-            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready, kWgLayers));
+            VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, nullptr, kWgOuter));
+            VITA_TRY(record(3 + L));
         } else {
             VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
             VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[1], 0));
@@ -1006,14 +1007,17 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
         if (dec_on_side) VITA_CHECK_HIP(hipStreamWaitEvent(st, side->join[0], 0));
         if (!layer_ready) VITA_TRY(record(2));
     } else if (layer_ready) {
-        // per-layer events: largest buckets first and a small one last, so that what a data-parallel caller still has to
-        // all-reduce when the backward ends is one layer's 8 MB, not the encoders' 18 MB (event order 0, 2, 1, 3 .. 3+L-1)
+        // 4 + L events, ordered for a data-parallel caller's link: the sections that make the most gradient bytes per unit of
+        // compute first (the layers' stacked weight gradients: 33.6 MB in 0.27 ms at B = 128; the encoders: 18 MB in 0.2 ms; the
+        // time path with the modulators: 15.7 MB in 0.2 ms), the 2 MB of the outer projections last — whatever the link's
+        // speed, little is left to send when the backward ends (event order 0, 3 .. 3+L-1, 2, 1, 3+L)
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready, kWgLayers));
         VITA_TRY(encoders_bwd(s.cs_part, st));
         VITA_TRY(record(2));
-        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, nullptr, kWgOuter));
         VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));
         VITA_TRY(record(1));
-        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, layer_ready, kWgLayers));
+        VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part, nullptr, kWgOuter));
+        VITA_TRY(record(3 + L));
     } else {
         VITA_TRY(flow_weight_grads(fc, g.flow, s.cs_part));
         VITA_TRY(time_path_bwd(fc, g.flow, T, s.cs_part));

@@ -959,9 +959,9 @@ def compute_loss(pw: PolicyHandle, cfg, obs_features: Tensor, actions: Tensor, t
         raise L.VitaHipError(f"compute_loss: losses needs {L.LOSS_COUNT} floats")
     dobs = torch.empty((B, pw.O), dtype=torch.float32, device=dev) if (need_dobs and grads is not None) else None
     ev = _event_handles(grad_ready_events, "compute_loss")
-    if ev is not None and len(ev) > 3:      # 3 + L events: per-layer readiness of the flow net's fc1 / fc2 gradients
-        if len(ev) != 3 + pw.w.flow.L:
-            raise L.VitaHipError(f"compute_loss: {len(ev)} grad_ready events; pass 3, or 3 + L = {3 + pw.w.flow.L}")
+    if ev is not None and len(ev) > 3:      # 4 + L events: per-section readiness of the flow net's gradients (vita_loss_config.grad_ready_layers)
+        if len(ev) != 4 + pw.w.flow.L:
+            raise L.VitaHipError(f"compute_loss: {len(ev)} grad_ready events; pass 3, or 4 + L = {4 + pw.w.flow.L}")
         cfg = L.LossConfig.from_buffer_copy(cfg)
         cfg.grad_ready_layers = 1
     external = pw.w.enc.kind == L.ENC_EXTERNAL

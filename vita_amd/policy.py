@@ -444,9 +444,9 @@ class VitaPolicy(nn.Module):
 
     # -- parameter plumbing --------------------------------------------------------------------------
     def hot_path_named_parameters(self):
-        """(name, parameter) of the trainable hot-path tensors in flat-buffer order: decoder, flow net (the layers' mlp
-        weights last, layer by layer, so that each gradient-ready event of reduce_plan covers ONE contiguous range and is one
-        all-reduce), encoders."""
+        """(name, parameter) of the trainable hot-path tensors in flat-buffer order: decoder, flow net (time path and modulators,
+        then the layers' mlp weights layer by layer, then the outer projections and the final norm: each gradient-ready event of
+        reduce_plan covers ONE contiguous range and is one all-reduce), encoders."""
         named = dict(self.named_parameters())
         out = []
         for prefixes in self.BUCKET_PREFIXES:
@@ -456,16 +456,22 @@ class VitaPolicy(nn.Module):
                     continue        # a torch module beside the fused path: its gradients come through autograd
                 if k.startswith(prefixes) and p.requires_grad:
                     group.append((k, p))
-            group.sort(key=lambda kp: self._layer_mlp_index(kp[0]))     # stable: module order within each class
+            group.sort(key=lambda kp: self._flow_event(kp[0]))     # stable: module order within each class
             out += group
         return out
 
-    def _layer_mlp_index(self, key: str) -> int:
-        """l for flow_net.layers.l.mlp.* of the default flow net (the tensors behind gradient-ready event 3 + l), else -1."""
+    def _flow_event(self, key: str) -> int:
+        """Gradient-ready event of a flow_net.* tensor of the default flow net (vita_loss_config.grad_ready_layers): 3 + l for
+        layers.l.mlp.*, 3 + L for the outer projections and the final norm, 1 for the time path (time_embed, time_modulator);
+        1 for everything else and for the MeanFlow net (its step records events 0..2)."""
         parts = key.split(".")
-        if not self.mean_flow and len(parts) > 3 and parts[0] == "flow_net" and parts[1] == "layers" and parts[3] == "mlp":
-            return int(parts[2])
-        return -1
+        if self.mean_flow or parts[0] != "flow_net":
+            return 1
+        if len(parts) > 3 and parts[1] == "layers" and parts[3] == "mlp":
+            return 3 + int(parts[2])
+        if parts[1] in ("input_proj", "norm", "out_proj"):
+            return 3 + int(self.config.policy.flow_net.num_layers)
+        return 1
 
     def frozen_prefixes(self) -> tuple:
         """Modules that receive no gradient under the freeze flags (vita_policy.py:119,153,174,183): the reference leaves
@@ -492,10 +498,10 @@ class VitaPolicy(nn.Module):
 
     def reduce_plan(self):
         """[(lo, hi, event)] over the flat gradient buffer, in the order the events fire inside the fused backward
-        (vita_loss_config.grad_ready_layers): the decoder (event 0); the encoders (event 2); the flow net other than the
-        layers' mlp weights (event 1: input / output projections, norm, time path, modulators); then each layer's mlp.fc1 /
-        mlp.fc2 gradients (event 3 + l, their stacked weight-gradient GEMMs run layer by layer) — the big buckets early, one
-        layer's 8 MB last.  The MeanFlow step records events 0, 1, 2 in that order."""
+        (vita_loss_config.grad_ready_layers): the decoder (event 0); each layer's mlp.fc1 / mlp.fc2 gradients (event 3 + l, their
+        stacked weight-gradient GEMMs run layer by layer); the encoders (event 2); the time path and the modulators (event 1); the
+        outer projections and the final norm (event 3 + L) — most gradient bytes per unit of compute first, 2 MB last.  The
+        MeanFlow step records events 0, 1, 2 in that order."""
         plan, off = [], 0
         named = self.hot_path_named_parameters()
         for k, p in named:
@@ -503,8 +509,7 @@ class VitaPolicy(nn.Module):
             if k.startswith("action_decoder."):
                 ev = 0
             elif k.startswith("flow_net."):
-                l = self._layer_mlp_index(k)
-                ev = 3 + l if l >= 0 else 1
+                ev = self._flow_event(k)
             else:
                 ev = 2
             if plan and plan[-1][2] == ev and plan[-1][1] == off:
@@ -512,7 +517,9 @@ class VitaPolicy(nn.Module):
             else:
                 plan.append((off, off + n, ev))
             off += n
-        order = {0: 0, 1: 2, 2: 1} if any(ev >= 3 for _, _, ev in plan) else {}   # 3 events only: they fire 0, 1, 2
+        # 4 + L events fire 0, 3 .. 3+L-1, 2, 1, 3+L; 3 events only: 0, 1, 2
+        last = max(ev for _, _, ev in plan)
+        order = {0: -1, 2: last - 0.6, 1: last - 0.3} if last >= 3 else {}
         plan.sort(key=lambda seg: (order.get(seg[2], seg[2]), seg[0]))
         return plan
 

@@ -6,7 +6,7 @@ parallelism on MI355X:
     zero_grad                                                not needed: gradients are overwritten, not accumulated
     loss, metrics = network.forward(batch)  (5 .item())      normalize kernels + ONE vita_compute_loss_f32 call,
     loss.backward()                                          forward and backward; no host sync
-    (no distributed code)                                    3 + L bucketed RCCL all-reduces started by events recorded
+    (no distributed code)                                    4 + L bucketed RCCL all-reduces started by events recorded
                                                              inside the backward, on a side stream
     clip_grad_norm_(1.0)         pass over all params        vita_sumsq_f32 (one read of the flat gradient)
     optimizer.step()  AdamW      pass over p, g, m, v        }
