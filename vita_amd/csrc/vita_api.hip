@@ -135,27 +135,27 @@ static int flow_eval(const vita_flownet_weights* w, const FlowWs& f, const float
         const float* shift = gamma + 2 * H;
         // LN + modulation as its own one-pass kernel (:18,44-45): fused into the GEMM's A staging it
         // cost every one of the FF/128 column tiles a statistics prologue (+20..40 us per GEMM).
-        if (H <= 2048) {
+        vita_linear_args a = lin(f.h, H, w->fc1_w[l], H, w->fc1_b[l], f.u, FF, B, FF, H, VITA_ACT_GELU_TANH);
+        a.pro = VITA_PRO_LN_MOD; a.ln_eps = 1e-6f;
+        a.pro_mul = scale; a.ld_pro_mul = ld_mod; a.pro_add = shift; a.ld_pro_add = ld_mod;
+        if (H <= 2048 && !gemm_f32_small_ln_eligible(a)) {
             VITA_TRY(launch_ln_mod(f.h, H, f.hn, H, B, H, 1e-6f, VITA_PRO_LN_MOD, scale, ld_mod, shift, ld_mod, s));
             VITA_TRY(gemm_f32(lin(f.hn, H, w->fc1_w[l], H, w->fc1_b[l], f.u, FF, B, FF, H, VITA_ACT_GELU_TANH), s));
-        } else {  // very wide nets: LayerNorm fused into the GEMM's A staging
-            vita_linear_args a = lin(f.h, H, w->fc1_w[l], H, w->fc1_b[l], f.u, FF, B, FF, H, VITA_ACT_GELU_TANH);
-            a.pro = VITA_PRO_LN_MOD; a.ln_eps = 1e-6f;
-            a.pro_mul = scale; a.ld_pro_mul = ld_mod; a.pro_add = shift; a.ld_pro_add = ld_mod;
+        } else {  // few rows: LayerNorm inside the few-row GEMM; very wide nets: fused into the generic GEMM's A staging
             VITA_TRY(gemm_f32(a, s));
         }
         vita_linear_args b = lin(f.u, FF, w->fc2_w[l], FF, w->fc2_b[l], f.h, H, B, H, FF, VITA_ACT_NONE);
         b.gate = gamma; b.ld_gate = ld_mod; b.resid = f.h; b.ld_resid = H;                            // :46
         VITA_TRY(gemm_f32(b, s));
     }
-    vita_linear_args o = lin(f.hn, H, w->out_w, H, w->out_b, Y, ldy, B, D, H, VITA_ACT_NONE);                      // :107
-    if (H <= 2048) {
-        VITA_TRY(launch_ln_mod(f.h, H, f.hn, H, B, H, 1e-5f, VITA_PRO_LN_AFFINE, w->norm_w, 0, w->norm_b, 0, s));  // :81,106
-    } else {
-        o.X = f.h; o.pro = VITA_PRO_LN_AFFINE; o.ln_eps = 1e-5f;
-        o.pro_mul = w->norm_w; o.ld_pro_mul = 0; o.pro_add = w->norm_b; o.ld_pro_add = 0;
-    }
+    vita_linear_args o = lin(f.h, H, w->out_w, H, w->out_b, Y, ldy, B, D, H, VITA_ACT_NONE);                       // :107
+    o.pro = VITA_PRO_LN_AFFINE; o.ln_eps = 1e-5f;
+    o.pro_mul = w->norm_w; o.ld_pro_mul = 0; o.pro_add = w->norm_b; o.ld_pro_add = 0;
     if (resid) { o.use_gate_scalar = 1; o.gate_scalar = dt; o.resid = resid; o.ld_resid = ld_resid; }
+    if (H <= 2048 && !gemm_f32_small_ln_eligible(o)) {
+        VITA_TRY(launch_ln_mod(f.h, H, f.hn, H, B, H, 1e-5f, VITA_PRO_LN_AFFINE, w->norm_w, 0, w->norm_b, 0, s));  // :81,106
+        o.X = f.hn; o.pro = VITA_PRO_NONE; o.pro_mul = o.pro_add = nullptr;
+    }
     VITA_TRY(gemm_f32(o, s));
     return VITA_OK;
 }

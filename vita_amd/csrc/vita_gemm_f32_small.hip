@@ -25,6 +25,11 @@ struct SmallParams {
     int kw;                  // k elements per wave (multiple of 8)
     int sk_splits, sk_k;     // grid-level split-K (k elements per split, multiple of 8)
     int* sk_counters;        // non-null: one zeroed counter per output tile; the last split to arrive finishes the tile (vita_splitk_fused.h)
+    // LayerNorm prologue of the 8-wave LDS kernel (K = the whole row, 8 x 64): A' = ((A - mean) * rstd) * m + add, m = mul (+ 1 for LN_MOD)
+    int pro_mod;             // 1: LN_MOD (m = 1 + mul), 0: LN_AFFINE
+    float ln_eps;
+    const float* pro_mul;    // (K): one modulation row for all rows of the call
+    const float* pro_add;
     EpiParams epi;
 };
 
@@ -173,8 +178,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_kernel(SmallParams p) 
 // wave's own) and reads the fragments back with ds_read_b128.  Same MFMAs in the same order on the same values as the
 // kernel above: the same bits.  A column operand (BCOL) keeps its four coalesced dword loads per chunk.
 // NW = 8 (k span 257..512: 64 k per wave, two blocks) halves the MFMA chain behind the DMA latency of a one-round launch.
-template <bool BCOL, int NW>
+// LN: the A rows are LayerNorm-ed (+ modulated) on the way from LDS to the MFMAs (NW = 8, K = 512 = the whole row, no grid
+// split): every wave sums its 64-k slice per row, the 8 partial sums meet in LDS (two passes: mean, then centred squares, as
+// ln_mod_kernel does), and each lane normalises its own fragments in registers.  Replaces a 4 us LayerNorm launch in front of
+// every few-row fc1 / out_proj of the sampler (one modulation row for the batch) by ~0.4 us inside it.
+template <bool BCOL, int NW, bool LN = false>
 __global__ __launch_bounds__(NW * 64) void gemm_f32_small_lds_kernel(SmallParams p) {
+    static_assert(!LN || (NW == 8 && !BCOL), "the LayerNorm prologue is built for the 8-wave row-operand kernel");
     constexpr int KB = 32, NBLK = 16 / NW;                    // 32-k blocks per wave: kw <= 128 (NW = 4) or 64 (NW = 8)
     constexpr int WREG = 2 * NBLK * 32 * KB;                  // floats of a wave's region
     extern __shared__ __attribute__((aligned(16))) float stage[];     // [NW][A: NBLK x 32 x 32 | B: NBLK x 32 x 32]
@@ -214,6 +224,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_lds_kernel(SmallParams
         if (e.resid) prs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
     }
     // (NW = 8: waves 4..7 issue no epilogue loads, so every wave's DMA counts below start from the same zero or are only ahead)
+    // LayerNorm prologue: this lane's modulation fragments (k = k0 + 8 c + 4 fh .. +3 of row fr), requested before the DMAs too
+    f32x4 lnm[LN ? 4 * NBLK : 1], lna[LN ? 4 * NBLK : 1];
+    if constexpr (LN) {
+        const float* pm = p.pro_mul + k0 + fh * 4;
+        const float* pa = p.pro_add + k0 + fh * 4;
+#pragma unroll
+        for (int c = 0; c < 4 * NBLK; ++c) {
+            lnm[c] = *reinterpret_cast<const f32x4*>(pm + c * 8);
+            lna[c] = *reinterpret_cast<const f32x4*>(pa + c * 8);
+        }
+    }
 
     // ---- DMA sources: lane l of the instruction for rows 8 j .. 8 j + 7 writes row 8 j + l / 8, chunk position l % 8,
     //      so it fetches chunk (l % 8) ^ swz(row) of that row's 128-byte piece
@@ -281,6 +302,52 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_lds_kernel(SmallParams
                 }
             }
         };
+        if constexpr (LN) {
+            __shared__ float ln_part[2][NW][32];
+            wait_vmcnt<0>();
+            f32x4 af[4 * NBLK];
+            float sm = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4 * NBLK; ++c) {
+                af[c] = *reinterpret_cast<const f32x4*>(sa + ((c >> 2) * 32 + fr) * KB + ((((c & 3) * 2 + fh) ^ fsw) * 4));
+                sm += (af[c][0] + af[c][1]) + (af[c][2] + af[c][3]);
+            }
+            sm += __shfl_xor(sm, 32, 64);
+            if (fh == 0) ln_part[0][wave][fr] = sm;
+            __syncthreads();
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) tot += ln_part[0][w][fr];
+            const float mu = tot / (float)p.K;
+            float q = 0.f;
+#pragma unroll
+            for (int c = 0; c < 4 * NBLK; ++c) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) { const float d = af[c][e4] - mu; q = fmaf(d, d, q); }
+            }
+            q += __shfl_xor(q, 32, 64);
+            if (fh == 0) ln_part[1][wave][fr] = q;
+            __syncthreads();
+            float qt = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) qt += ln_part[1][w][fr];
+            const float rstd = 1.0f / sqrtf(qt / (float)p.K + p.ln_eps);
+#pragma unroll
+            for (int c = 0; c < 4 * NBLK; ++c) {
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) {
+                    const float nrm = (af[c][e4] - mu) * rstd;
+                    const float m = p.pro_mod ? (lnm[c][e4] + 1.0f) : lnm[c][e4];
+                    af[c][e4] = nrm * m + lna[c][e4];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < 4 * NBLK; ++c) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(sb + ((c >> 2) * 32 + fr) * KB + ((((c & 3) * 2 + fh) ^ fsw) * 4));
+#pragma unroll
+                for (int e4 = 0; e4 < 4; ++e4) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][e4], b[e4], acc, 0, 0, 0);
+            }
+        } else
         // the wave's DMAs complete in order: block kb is there once at most 8 * (NBLK - 1 - kb) of them are still out
         if constexpr (NBLK == 4) {
             wait_vmcnt<24>(); block(0);
@@ -357,12 +424,29 @@ __global__ __launch_bounds__(NW * 64) void gemm_f32_small_lds_kernel(SmallParams
 }
 
 // Shapes this kernel is meant for.  k_split = 0: the caller has no split-K scratch.
+// The LayerNorm prologue this file builds: the 8-wave LDS kernel on a whole 512-long row (K = 8 x 64), row operands, no grid split.
+bool gemm_f32_small_ln_eligible(const vita_linear_args& a) {
+#ifdef VITA_NO_SMALL_GEMM
+    return false;
+#endif
+    static const bool off = (getenv("VITA_SMALL_NO_LDS") != nullptr && atoi(getenv("VITA_SMALL_NO_LDS")) != 0) ||
+                            (getenv("VITA_NO_SMALL_LN") != nullptr && atoi(getenv("VITA_NO_SMALL_LN")) != 0);
+    auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
+    if (off || a.a_col || a.b_col || (a.pro != VITA_PRO_LN_MOD && a.pro != VITA_PRO_LN_AFFINE)) return false;
+    if (a.M <= 0 || a.M > 512 || a.N < 32 || a.K != 512 || a.ldx % 4 != 0 || a.ldw % 4 != 0 || !al(a.X) || !al(a.W)) return false;
+    if (!a.pro_mul || !a.pro_add || !al(a.pro_mul) || !al(a.pro_add) || a.ld_pro_mul % 4 != 0 || a.ld_pro_add % 4 != 0) return false;
+    if (a.ld_pro_mul != 0 || a.ld_pro_add != 0) return false;     // one modulation row for the batch (the sampler); per-row tables measured no gain
+    const double traffic = ((double)((a.M + 31) / 32) * a.N + (double)((a.N + 31) / 32) * a.M) * a.K * 4.0;
+    return traffic <= 96e6;
+}
+
 bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws) {
 #ifdef VITA_NO_SMALL_GEMM
     return false;
 #endif
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-    if (a.a_col || a.pro != VITA_PRO_NONE || a.M <= 0 || a.M > 512 || a.N < 32 || a.K < 64) return false;
+    if (a.pro != VITA_PRO_NONE) return gemm_f32_small_ln_eligible(a);
+    if (a.a_col || a.M <= 0 || a.M > 512 || a.N < 32 || a.K < 64) return false;
     if (a.K % 4 != 0 || a.ldx % 4 != 0 || !al(a.X)) return false;
     if (!a.b_col && (a.ldw % 4 != 0 || !al(a.W))) return false;
     // one 32 x 32 tile per workgroup re-reads operands (M/32 + N/32) times: keep the L2 traffic of a launch bounded
@@ -396,6 +480,15 @@ int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* 
     p.kw = ((kspan + nw - 1) / nw + 7) & ~7;
     const unsigned grid = (unsigned)(p.tiles_n * ((a.M + 31) / 32) * (p.sk_splits > 1 ? p.sk_splits : 1));
     static const bool no_lds = getenv("VITA_SMALL_NO_LDS") != nullptr && atoi(getenv("VITA_SMALL_NO_LDS")) != 0;
+    if (a.pro != VITA_PRO_NONE) {       // LayerNorm prologue (gemm_f32_small_ln_eligible): 8 waves x 64 k, no grid split
+        VITA_REQUIRE(gemm_f32_small_ln_eligible(a) && p.sk_splits <= 1 && nw == 8 && p.kw == 64, "few-row GEMM: LayerNorm prologue on an unsupported call");
+        p.pro_mod = a.pro == VITA_PRO_LN_MOD ? 1 : 0; p.ln_eps = a.ln_eps;
+        p.pro_mul = a.pro_mul; p.pro_add = a.pro_add;
+        constexpr size_t lds_ln = (size_t)4 * 2 * 4 * 32 * 32 * sizeof(float);
+        hipLaunchKernelGGL((gemm_f32_small_lds_kernel<false, 8, true>), dim3(grid), dim3(512), lds_ln, stream, p);
+        VITA_CHECK_HIP(hipGetLastError());
+        return VITA_OK;
+    }
     if (p.kw <= 512 / nw && !no_lds) {      // operands through LDS (coalesced DMA): the same bits, faster loads
         constexpr size_t lds = (size_t)4 * 2 * 4 * 32 * 32 * sizeof(float);      // 128 KB either way: NW x NBLK = 16 blocks of 2 x 4 KB
         if (nw == 4) {

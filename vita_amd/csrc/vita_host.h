@@ -71,6 +71,10 @@ struct Carver {
     }
 };
 
+// true when gemm_f32() will run this call's LayerNorm prologue (a.pro) inside the few-row kernel — instead of a LayerNorm launch
+// in front of it (vita_gemm_f32_small.hip); callers that get false keep launch_ln_mod + a plain GEMM
+bool gemm_f32_small_ln_eligible(const vita_linear_args& a);
+
 // Column sums (bias gradients) of several few-row matrices in one launch; matrices of more than 2048 rows go straight to
 // vita_colsum_f32.  flush() before the results are needed and before a source buffer is overwritten.
 constexpr int kColsumJobs = 16;
