@@ -322,6 +322,28 @@ int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float*
                             double ema_decay, vita_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Dataset -> device batches on a replay buffer resident in HBM.
+ * AVAlohaDataset.__getitem__ (gym_av_aloha/datasets/av_aloha_dataset.py:349-372) + default_collate for a batch of frame
+ * indices: for b < B, j < T, with i = idx[b], ep = ep_index[i] (replay_buffer['episode_index'], :350) and
+ * (lo, hi) = (ep_from[ep], ep_to[ep]) (episode_data_index, :308-309):
+ *     q = max(lo, min(hi - 1, i + delta[j]))                         _get_query_indices, :310-313
+ *     out[b, j] = src[q]
+ *     is_pad[b, j] = (i + delta[j] < lo) | (i + delta[j] >= hi)      :314-319   (is_pad may be NULL)
+ * delta: the key's delta indices, round(delta_timestamp * fps) (lerobot get_delta_indices).  Every pointer is device memory;
+ * indices are int64 as torch.LongTensor holds them.
+ * vita_gather_window_f32: src (N, R) float rows with row stride ld_src (states, actions, precomputed camera latents) ->
+ *     out (B, T, R).
+ * vita_gather_window_u8_nchw_f32: src (N, H, W, C) uint8 images -> out (B, T, C, H, W) float32 = value / 255, the
+ *     `.type(torch.float32).permute(0, 3, 1, 2) / 255.0` of :355-356 (C in {1, 3, 4}; B * T <= 65535 per call).
+ * --------------------------------------------------------------------------------------- */
+int vita_gather_window_f32(const float* src, int64_t ld_src, int32_t R, const int64_t* idx, int32_t B, const int64_t* delta, int32_t T,
+                           const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, float* out, uint8_t* is_pad,
+                           vita_stream_t stream);
+int vita_gather_window_u8_nchw_f32(const uint8_t* src, int32_t H, int32_t W, int32_t C, const int64_t* idx, int32_t B, const int64_t* delta,
+                                   int32_t T, const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, float* out, uint8_t* is_pad,
+                                   vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training forward + backward of the whole hot path in one call.
  * --------------------------------------------------------------------------------------- */
 enum { VITA_ENC_CNN = 0, VITA_ENC_SIMPLE = 1,

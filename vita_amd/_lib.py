@@ -203,6 +203,9 @@ SIGNATURES = {
     "vita_action_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderWeights), C.c_int32]),
     "vita_action_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderWeights), c_fp, c_fp, C.c_int64, C.c_int32, c_fp, C.c_size_t,
                                                   c_fp]),
+    "vita_gather_window_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "vita_gather_window_u8_nchw_f32": (C.c_int, [c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp,
+                                                 c_fp, c_fp, c_fp]),
     "vita_colsum_partials_count": (C.c_int64, [C.c_int32]),
     "vita_colsum_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int32, c_fp]),
     "vita_im2col_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),

@@ -56,6 +56,9 @@ class Config(dict):
         return self
 
 
+# flare/configs/task/*.yaml: fps (the dataset's frame rate: delta timestamps = index / fps, dataset_utils.py:85-92)
+TASK_FPS = {"pusht": 10, "hook_package": 8.333333333, "thread_needle": 8.333333333, "robomimic_square": 20}
+
 # flare/configs/task/*.yaml: (image_keys, state_dim, action_dim)
 TASKS = {
     "pusht": (["observation.image"], 2, 2),                                             # pusht.yaml:27-33
@@ -78,7 +81,7 @@ def default_config(task: str = "hook_package") -> Config:
         "train": {"steps": 100000, "batch_size": 128, "grad_clip_norm": 1.0},
         "val": {"batch_size": 512, "eval_n_envs": 25},
         "task": {"name": task, "image_keys": image_keys, "state_key": "observation.state", "action_key": "action",
-                 "state_dim": state_dim, "action_dim": action_dim},
+                 "state_dim": state_dim, "action_dim": action_dim, "fps": TASK_FPS[task]},
         # policy/vita.yaml:3-57
         "policy": {
             "name": "vita", "runner": "policy_trainer", "action_horizon": 8, "pred_horizon": 16, "obs_horizon": 1,
