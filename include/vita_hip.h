@@ -344,6 +344,21 @@ int vita_gather_window_u8_nchw_f32(const uint8_t* src, int32_t H, int32_t W, int
                                    vita_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * The observer's elementwise tail.  ResNetObserver's backbone (flare/policies/observers/resnet_observer.py:40-44:
+ * resnet18 with norm_layer = torchvision FrozenBatchNorm2d) follows every convolution with  x * scale[c] + shift[c]  (scale =
+ * weight * rsqrt(running_var + eps), shift = bias - running_mean * scale), the residual blocks add the shortcut, and a ReLU follows.
+ * x, res, y: (rows / C, C, HW) contiguous float32 (NCHW with HW = H * W); res may be NULL; relu in {0, 1}.
+ *     y = act((x * scale[c] + shift[c]) + res),   act = ReLU (NaN propagates, as torch.relu) or identity
+ * One pass instead of torch's three to four; the arithmetic order is torch's, so the result is bitwise the unfused one.
+ * _bwd: dx = g * scale[c], dres = g (NULL: not wanted) with g = dy where y > 0 else 0 (relu) or g = dy; y is the forward's output
+ * (may be NULL when relu == 0).  scale and shift carry no gradient (frozen statistics).  rows * HW < 2^32.
+ * --------------------------------------------------------------------------------------- */
+int vita_channel_affine_relu_f32(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t rows, int32_t C,
+                                 int32_t HW, int32_t relu, vita_stream_t stream);
+int vita_channel_affine_relu_bwd_f32(const float* dy, const float* y, const float* scale, float* dx, float* dres, int64_t rows, int32_t C,
+                                     int32_t HW, int32_t relu, vita_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Training forward + backward of the whole hot path in one call.
  * --------------------------------------------------------------------------------------- */
 enum { VITA_ENC_CNN = 0, VITA_ENC_SIMPLE = 1,

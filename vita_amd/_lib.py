@@ -206,6 +206,8 @@ SIGNATURES = {
     "vita_gather_window_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
     "vita_gather_window_u8_nchw_f32": (C.c_int, [c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp,
                                                  c_fp, c_fp, c_fp]),
+    "vita_channel_affine_relu_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
+    "vita_channel_affine_relu_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_colsum_partials_count": (C.c_int64, [C.c_int32]),
     "vita_colsum_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int32, c_fp]),
     "vita_im2col_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),

@@ -59,6 +59,10 @@ class Config(dict):
 # flare/configs/task/*.yaml: fps (the dataset's frame rate: delta timestamps = index / fps, dataset_utils.py:85-92)
 TASK_FPS = {"pusht": 10, "hook_package": 8.333333333, "thread_needle": 8.333333333, "robomimic_square": 20}
 
+# flare/configs/task/*.yaml:3-4: (resize_shape, crop_shape) of the observer
+TASK_IMAGE_SHAPES = {"pusht": ([96, 96], [84, 84]), "hook_package": ([240, 320], [224, 308]), "thread_needle": ([240, 320], [224, 308]),
+                     "robomimic_square": ([256, 256], [224, 224])}
+
 # flare/configs/task/*.yaml: (image_keys, state_dim, action_dim)
 TASKS = {
     "pusht": (["observation.image"], 2, 2),                                             # pusht.yaml:27-33
@@ -75,6 +79,7 @@ def default_config(task: str = "hook_package") -> Config:
     return Config({
         # default_policy.yaml:15-51
         "seed": 42, "device": "cuda:0",
+        "resize_shape": TASK_IMAGE_SHAPES[task][0], "crop_shape": TASK_IMAGE_SHAPES[task][1],
         "optimizer_lr": 1e-4, "optimizer_lr_backbone": 1e-5, "optimizer_betas": [0.95, 0.999], "optimizer_eps": 1e-8,
         "optimizer_weight_decay": 1e-6, "scheduler_name": "cosine", "scheduler_warmup_steps": 500,
         "use_ema": True, "ema_power": 0.75,

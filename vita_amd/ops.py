@@ -572,6 +572,52 @@ def _norm(fn_name: str, x: Tensor, mean: Tensor, std: Tensor) -> Tensor:
     return y
 
 
+class _ChannelAffineReLU(torch.autograd.Function):
+    """vita_channel_affine_relu_f32 / _bwd_f32 (include/vita_hip.h)."""
+
+    @staticmethod
+    def forward(ctx, x, res, scale, shift, relu):
+        lib = L.load()
+        x = _f32(x, "channel_affine_relu: x").contiguous()
+        if x.dim() < 2 or scale.shape != (x.shape[1],) or shift.shape != scale.shape:
+            raise L.VitaHipError(f"channel_affine_relu: x {tuple(x.shape)} against scale {tuple(scale.shape)} / shift {tuple(shift.shape)}")
+        if res is not None:
+            res = _f32(res, "channel_affine_relu: res").contiguous()
+            if res.shape != x.shape:
+                raise L.VitaHipError(f"channel_affine_relu: shortcut {tuple(res.shape)} against x {tuple(x.shape)}")
+        scale = _f32(scale, "channel_affine_relu: scale").contiguous()
+        shift = _f32(shift, "channel_affine_relu: shift").contiguous()
+        Cn = x.shape[1]
+        hw = 1
+        for d in x.shape[2:]:
+            hw *= d
+        y = torch.empty_like(x)
+        L.check(lib.vita_channel_affine_relu_f32(x.data_ptr(), res.data_ptr() if res is not None else None, scale.data_ptr(), shift.data_ptr(),
+                                                 y.data_ptr(), x.shape[0] * Cn, Cn, hw, int(relu), _stream(x)), "vita_channel_affine_relu_f32")
+        ctx.relu, ctx.has_res, ctx.dims = bool(relu), res is not None, (x.shape[0] * Cn, Cn, hw)
+        ctx.save_for_backward(y if relu else None, scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        y, scale = ctx.saved_tensors
+        dy = _f32(dy, "channel_affine_relu: dy").contiguous()
+        dx = torch.empty_like(dy)
+        dres = torch.empty_like(dy) if ctx.has_res and ctx.needs_input_grad[1] else None
+        rows, Cn, hw = ctx.dims
+        L.check(lib.vita_channel_affine_relu_bwd_f32(dy.data_ptr(), y.data_ptr() if y is not None else None, scale.data_ptr(), dx.data_ptr(),
+                                                     dres.data_ptr() if dres is not None else None, rows, Cn, hw, int(ctx.relu), _stream(dy)),
+                "vita_channel_affine_relu_bwd_f32")
+        return dx, dres, None, None, None
+
+
+def channel_affine_relu(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[Tensor] = None, relu: bool = True) -> Tensor:
+    """act((x * scale[c] + shift[c]) + res) over (N, C, ...) in one pass, with its backward (frozen batch norm + shortcut + ReLU of the
+    observer's ResNet18, vita_amd/observers.py)."""
+    return _ChannelAffineReLU.apply(x, res, scale, shift, relu)
+
+
 def normalize(x, mean, std): return _norm("vita_normalize_f32", x, mean, std)
 def unnormalize(x, mean, std): return _norm("vita_unnormalize_f32", x, mean, std)
 

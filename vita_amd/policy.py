@@ -7,10 +7,11 @@ generate_actions / select_action / compute_loss runs in libvita_hip.so through t
   * training:   vita_compute_loss_f32      (forward + hand-written backward, one call)
 There is no CPU or torch fallback: on a CPU tensor the ops raise VitaHipError.
 
-Out of scope here: the ResNet18 observer.  `observer` is pluggable (any nn.Module mapping the
-batch to (B, O) features); the default FeatureObserver consumes precomputed camera latents
-(batch["observation.features"], 512 per camera) + the state, in the reference's concat order
-(resnet_observer.py:80-97: state first).
+The observer sits in front of that path as a torch module: `observer="resnet18"` builds
+vita_amd.observers.ResNetObserver from the config as vita_policy.py:43-50 does (camera frames in, backbone trained through
+d loss / d features); any nn.Module mapping the batch to (B, O) features can be passed instead; the default FeatureObserver
+consumes precomputed camera latents (batch["observation.features"], 512 per camera) + the state, in the reference's concat
+order (resnet_observer.py:80-97: state first).
 """
 from __future__ import annotations
 
@@ -195,7 +196,7 @@ class FeatureObserver(nn.Module):
     def forward(self, batch):
         if self.feature_key not in batch:
             raise KeyError(f"batch has no '{self.feature_key}': pass precomputed camera latents, or construct VitaPolicy with "
-                           "observer=<module producing (B, O) features> (the ResNet18 observer is out of this build's scope)")
+                           "observer='resnet18' (camera frames in) or observer=<module producing (B, O) features>")
         return torch.cat([batch[self.state_key].flatten(start_dim=1), batch[self.feature_key].flatten(start_dim=1)], dim=1)
 
 
@@ -310,9 +311,11 @@ class VitaPolicy(nn.Module):
     # flat-buffer segment order = the order gradients become final in the backward pass (vita_loss_step.hip)
     BUCKET_PREFIXES = (("action_decoder.",), ("flow_net.",), ("action_encoder.", "obs_encoder."))
 
-    def __init__(self, config, stats, observer: Optional[nn.Module] = None, action_encoder: Optional[nn.Module] = None,
+    def __init__(self, config, stats, observer=None, action_encoder: Optional[nn.Module] = None,
                  action_decoder: Optional[nn.Module] = None):
-        """action_encoder: an nn.Module mapping normalised actions (B, T, A) to latents (B, latent_dim) that replaces the
+        """observer: None (precomputed camera latents, FeatureObserver), "resnet18" (vita_amd.observers.ResNetObserver built from
+        the config, vita_policy.py:43-50), or an nn.Module mapping the batch to (B, obs_dim) features.
+        action_encoder: an nn.Module mapping normalised actions (B, T, A) to latents (B, latent_dim) that replaces the
         configured one (for instance the reference's own module of a non-default encoder type).  It runs under torch autograd
         and meets the fused path at the latents (VITA_ENC_EXTERNAL, vita_amd/encoders.py); `encoder_type: transformer` builds
         vita_amd.encoders.TransformerActionEncoder this way.  Under `use_variational` the module returns the (B, 2 * latent_dim)
@@ -335,6 +338,12 @@ class VitaPolicy(nn.Module):
         self._action_queue = None
         # vita_policy.py:41-74
         self.num_sampling_steps = pol.flow_matcher.num_sampling_steps
+        if isinstance(observer, str):
+            if observer != "resnet18":
+                raise ValueError(f"observer {observer!r}: 'resnet18', an nn.Module or None")
+            from .observers import ResNetObserver
+            observer = ResNetObserver(state_key=task.state_key, image_keys=task.image_keys, resize_shape=config.resize_shape,
+                                      crop_shape=config.crop_shape, state_dim=task.state_dim, tokenize=False)    # :43-50
         self.observer = observer if observer is not None else FeatureObserver(task.state_key)
         self.obs_dim = len(task.image_keys) * 512 + task.state_dim
         self.FM = get_flow_matcher(**dict(pol.flow_matcher))
