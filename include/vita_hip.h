@@ -350,13 +350,23 @@ int vita_gather_window_u8_nchw_f32(const uint8_t* src, int32_t H, int32_t W, int
  * x, res, y: (rows / C, C, HW) contiguous float32 (NCHW with HW = H * W); res may be NULL; relu in {0, 1}.
  *     y = act((x * scale[c] + shift[c]) + res),   act = ReLU (NaN propagates, as torch.relu) or identity
  * One pass instead of torch's three to four; the arithmetic order is torch's, so the result is bitwise the unfused one.
- * _bwd: dx = g * scale[c], dres = g (NULL: not wanted) with g = dy where y > 0 else 0 (relu) or g = dy; y is the forward's output
+ * _bwd: dx = g * scale[c], dres = g (NULL: not wanted) with g = 0 where y <= 0 else dy (relu; torch's threshold_backward) or g = dy; y is the forward's output
  * (may be NULL when relu == 0).  scale and shift carry no gradient (frozen statistics).  rows * HW < 2^32.
  * --------------------------------------------------------------------------------------- */
 int vita_channel_affine_relu_f32(const float* x, const float* res, const float* scale, const float* shift, float* y, int64_t rows, int32_t C,
                                  int32_t HW, int32_t relu, vita_stream_t stream);
 int vita_channel_affine_relu_bwd_f32(const float* dy, const float* y, const float* scale, float* dx, float* dres, int64_t rows, int32_t C,
                                      int32_t HW, int32_t relu, vita_stream_t stream);
+/* The stem (conv1 -> bn1 -> relu -> maxpool of torchvision's resnet18): frozen norm + ReLU + MaxPool2d(kernel 3, stride 2, padding 1)
+ * in one pass.  x: (planes / C, C, H, W); y: (planes / C, C, Ho, Wo) with Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1; idx: one byte per
+ * element of y, the winning window position kh * 3 + kw (the first maximum in row-major order, NaN wins: torch's rule), or 255 where
+ * the window's maximum is <= 0 (the ReLU passes no gradient there).
+ * _bwd: dx[h, w] = scale[c] * sum of dy over the windows that (h, w) won (idx != 255), windows in (row, column) order — bitwise
+ * torch's max_pool2d backward followed by the ReLU's and the norm's.  planes <= 65535 per call. */
+int vita_affine_relu_maxpool3s2_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, int64_t planes, int32_t C,
+                                    int32_t H, int32_t W, vita_stream_t stream);
+int vita_affine_relu_maxpool3s2_bwd_f32(const float* dy, const uint8_t* idx, const float* scale, float* dx, int64_t planes, int32_t C, int32_t H,
+                                        int32_t W, vita_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Training forward + backward of the whole hot path in one call.

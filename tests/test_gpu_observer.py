@@ -195,3 +195,58 @@ def test_backbone_with_the_fused_tail_equals_the_torch_ops(monkeypatch):
     assert nerr(outs["0"][0], outs["1"][0]) <= 1e-5
     for k in outs["0"][1]:
         assert nerr(outs["0"][1][k], outs["1"][1][k]) <= 1e-4, k      # MIOpen's weight-gradient reductions are not run-to-run bitwise
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 9, 11), (3, 8, 42, 42), (1, 64, 112, 154), (2, 4, 1, 1), (2, 5, 2, 7), (0, 4, 6, 6)])
+def test_stem_tail_is_bitwise_norm_relu_maxpool(shape):
+    from vita_amd import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g).to(DEV).requires_grad_(True)
+    scale = (torch.rand(shape[1], generator=g) + 0.5).to(DEV)
+    shift = (0.3 * torch.randn(shape[1], generator=g)).to(DEV)
+    y = ops.affine_relu_maxpool(x, scale, shift)
+    dy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(dy)
+    got = (y.detach().clone(), x.grad.clone())
+    x.grad = None
+    want = F.max_pool2d(torch.relu(x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)), 3, 2, 1)
+    want.backward(dy)
+    assert got[0].shape == want.shape and torch.equal(got[0], want.detach())
+    assert torch.equal(got[1], x.grad)
+
+
+def test_stem_tail_splits_more_planes_than_one_launch_takes(monkeypatch):
+    from vita_amd import ops
+    import torch.nn.functional as F
+    monkeypatch.setattr(ops._AffineReLUMaxPool, "MAX_PLANES", 7)        # 3 channels: two images per launch
+    x = torch.randn(5, 3, 8, 10, generator=torch.Generator().manual_seed(0)).to(DEV).requires_grad_(True)
+    scale, shift = torch.full((3,), 1.25, device=DEV), torch.tensor([0.1, -0.2, 0.0], device=DEV)
+    y = ops.affine_relu_maxpool(x, scale, shift)
+    y.sum().backward()
+    got = x.grad.clone()
+    x.grad = None
+    want = F.max_pool2d(torch.relu(x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)), 3, 2, 1)
+    want.sum().backward()
+    assert torch.equal(y.detach(), want.detach()) and torch.equal(got, x.grad)
+
+
+@pytest.mark.parametrize("W", [12, 13])
+def test_stem_tail_nan_and_nonpositive_windows_follow_torch(W):
+    from vita_amd import ops
+    import torch.nn.functional as F
+    x = torch.randn(2, 3, 10, W, generator=torch.Generator().manual_seed(W)).to(DEV)
+    x[0, 0, 5, 5] = float("nan")
+    x[1, 1] = -x[1, 1].abs()             # a plane whose every window has maximum 0 after the ReLU: no gradient anywhere
+    x.requires_grad_(True)
+    scale, shift = torch.tensor([1.5, 0.75, 1.0], device=DEV), torch.zeros(3, device=DEV)
+    y = ops.affine_relu_maxpool(x, scale, shift)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(1)).to(DEV)
+    y.backward(dy)
+    got = (y.detach().clone(), x.grad.clone())
+    x.grad = None
+    want = F.max_pool2d(torch.relu(x * scale.reshape(1, -1, 1, 1) + shift.reshape(1, -1, 1, 1)), 3, 2, 1)
+    want.backward(dy)
+    assert torch.isnan(want).any() and float(x.grad[1, 1].abs().max()) == 0.0
+    assert torch.equal(torch.nan_to_num(got[0], nan=77.0), torch.nan_to_num(want.detach(), nan=77.0))
+    assert torch.equal(torch.nan_to_num(got[1], nan=77.0), torch.nan_to_num(x.grad, nan=77.0))

@@ -208,6 +208,8 @@ SIGNATURES = {
                                                  c_fp, c_fp, c_fp]),
     "vita_channel_affine_relu_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_channel_affine_relu_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
+    "vita_affine_relu_maxpool3s2_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
+    "vita_affine_relu_maxpool3s2_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_colsum_partials_count": (C.c_int64, [C.c_int32]),
     "vita_colsum_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, C.c_int32, c_fp, c_fp, C.c_int32, c_fp]),
     "vita_im2col_k5s2_f32": (C.c_int, [c_fp, c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp]),

@@ -67,9 +67,9 @@ __global__ __launch_bounds__(256) void channel_affine_bwd_v4_kernel(AffineBwdArg
         if (i >= a.n) return;
         const float s = a.scale[(i / a.hw) % a.C];
         float4 g = g4[i];
-        if (RELU) {       // threshold_backward: the gradient passes where the output is > 0
+        if (RELU) {       // threshold_backward: the gradient is dropped where the output is <= 0 (a NaN output passes it)
             const float4 y = y4[i];
-            g.x = y.x > 0.0f ? g.x : 0.0f; g.y = y.y > 0.0f ? g.y : 0.0f; g.z = y.z > 0.0f ? g.z : 0.0f; g.w = y.w > 0.0f ? g.w : 0.0f;
+            g.x = y.x <= 0.0f ? 0.0f : g.x; g.y = y.y <= 0.0f ? 0.0f : g.y; g.z = y.z <= 0.0f ? 0.0f : g.z; g.w = y.w <= 0.0f ? 0.0f : g.w;
         }
         if (RES) dr4[i] = g;
         g.x *= s; g.y *= s; g.z *= s; g.w *= s;
@@ -84,10 +84,143 @@ __global__ __launch_bounds__(256) void channel_affine_bwd_kernel(AffineBwdArgs a
         const unsigned i = (blockIdx.x * 4u + u) * 256u + threadIdx.x;
         if (i >= a.n) return;
         float g = a.dy[i];
-        if (RELU) g = a.y[i] > 0.0f ? g : 0.0f;
+        if (RELU) g = a.y[i] <= 0.0f ? 0.0f : g;
         if (RES) a.dres[i] = g;
         a.dx[i] = g * a.scale[(i / a.hw) % a.C];
     }
+}
+
+// ---- the stem: frozen norm + ReLU + MaxPool2d(3, stride 2, padding 1) in one pass ------------------------------------------------
+// Forward reads the convolution's output once (565 MB at 128 frames) and writes only the pooled map (a quarter of it) and one
+// byte per pooled element: which of the window's 9 positions won (torch's rule: the first maximum in row-major order, NaN wins).
+// A window whose maximum is <= 0 passes no gradient through the ReLU: its byte says so (kNoGrad).
+// Backward therefore needs neither the convolution's output nor any activation: a pixel receives dy of every window it won.
+// Sums run over windows in (row, column) order, as torch's max_pool2d backward does.
+// Even W (the reference's crops: 308, 224, 84): a lane holds two adjacent columns (float2 loads and stores, whole cache lines) and
+// gets the third from its neighbour lane; odd W takes the one-element-per-lane kernels.
+constexpr unsigned char kNoGrad = 255;
+#define VITA_POOL_UPDATE(v, k) do { const float v__ = (v); if (arg < 0 || v__ > best || v__ != v__) { best = v__; arg = (k); } } while (0)
+struct StemArgs {
+    const float* x; const float* scale; const float* shift; float* y; unsigned char* idx;
+    unsigned planes, C, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void stem_tail_kernel(StemArgs a) {
+    const unsigned wo = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const unsigned ho = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const unsigned plane = blockIdx.z;
+    if (wo >= a.Wo || ho >= a.Ho) return;
+    const unsigned c = plane % a.C;
+    const float s = a.scale[c], b = a.shift[c];
+    const float* xp = a.x + (size_t)plane * a.H * a.W;
+    float best = -INFINITY;
+    int arg = -1;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = (int)(2u * ho) - 1 + kh;
+        if (h < 0 || h >= (int)a.H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int w = (int)(2u * wo) - 1 + kw;
+            if (w < 0 || w >= (int)a.W) continue;
+            const float v = relu_nan(xp[(size_t)h * a.W + w] * s + b);
+            if (arg < 0 || v > best || v != v) { best = v; arg = kh * 3 + kw; }
+        }
+    }
+    const size_t o = ((size_t)plane * a.Ho + ho) * a.Wo + wo;
+    a.y[o] = best;
+    a.idx[o] = best <= 0.0f ? kNoGrad : (unsigned char)arg;
+}
+
+__global__ __launch_bounds__(256) void stem_tail_even_kernel(StemArgs a) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wo = blockIdx.x * 64u + lane;
+    const unsigned ho = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const unsigned plane = blockIdx.z;
+    if (ho >= a.Ho) return;                       // uniform over the wave: the lanes below exchange columns
+    const bool live = wo < a.Wo, has_left = wo > 0;
+    const unsigned c = plane % a.C;
+    const float s = a.scale[c], b = a.shift[c];
+    const float* xp = a.x + (size_t)plane * a.H * a.W;
+    float best = -INFINITY;
+    int arg = -1;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = (int)(2u * ho) - 1 + kh;
+        if (h < 0 || h >= (int)a.H) continue;
+        const float* row = xp + (size_t)h * a.W;
+        float2 v = make_float2(0.0f, 0.0f);
+        if (live) v = *reinterpret_cast<const float2*>(row + 2u * wo);
+        v.x = relu_nan(v.x * s + b);
+        v.y = relu_nan(v.y * s + b);
+        float left = __shfl_up(v.y, 1);
+        if (lane == 0 && has_left && live) left = relu_nan(row[2u * wo - 1u] * s + b);
+        if (has_left) VITA_POOL_UPDATE(left, kh * 3 + 0);
+        VITA_POOL_UPDATE(v.x, kh * 3 + 1);
+        VITA_POOL_UPDATE(v.y, kh * 3 + 2);
+    }
+    if (!live) return;
+    const size_t o = ((size_t)plane * a.Ho + ho) * a.Wo + wo;
+    a.y[o] = best;
+    a.idx[o] = best <= 0.0f ? kNoGrad : (unsigned char)arg;
+}
+
+struct StemBwdArgs {
+    const float* dy; const unsigned char* idx; const float* scale; float* dx;
+    unsigned planes, C, H, W, Ho, Wo;
+};
+
+__global__ __launch_bounds__(256) void stem_tail_bwd_kernel(StemBwdArgs a) {
+    const unsigned w = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const unsigned h = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const unsigned plane = blockIdx.z;
+    if (w >= a.W || h >= a.H) return;
+    const size_t po = (size_t)plane * a.Ho * a.Wo;
+    // windows ho with 2 ho - 1 <= h <= 2 ho + 1
+    const int ho_lo = (int)(h / 2u), ho_hi = (int)((h + 1u) / 2u);
+    const int wo_lo = (int)(w / 2u), wo_hi = (int)((w + 1u) / 2u);
+    float g = 0.0f;
+    for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+        if (ho >= (int)a.Ho) break;
+        const int kh = (int)h - (2 * ho - 1);
+        for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+            if (wo >= (int)a.Wo) break;
+            const int kw = (int)w - (2 * wo - 1);
+            const size_t o = po + (size_t)ho * a.Wo + wo;
+            if (a.idx[o] == (unsigned char)(kh * 3 + kw)) g += a.dy[o];
+        }
+    }
+    a.dx[((size_t)plane * a.H + h) * a.W + w] = g * a.scale[plane % a.C];
+}
+
+__global__ __launch_bounds__(256) void stem_tail_bwd_even_kernel(StemBwdArgs a) {
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned j = blockIdx.x * 64u + lane;            // columns 2j, 2j + 1
+    const unsigned h = blockIdx.y * 4u + (threadIdx.x >> 6);
+    const unsigned plane = blockIdx.z;
+    if (h >= a.H) return;                         // uniform over the wave
+    const bool live = j < a.Wo, has_right = j + 1u < a.Wo;
+    const size_t po = (size_t)plane * a.Ho * a.Wo;
+    float ga = 0.0f, gb = 0.0f;
+    const unsigned ho0 = h / 2u, nwin = (h & 1u) ? 2u : 1u;
+    for (unsigned t = 0; t < nwin; ++t) {
+        const unsigned ho = ho0 + t;
+        if (ho >= a.Ho) break;
+        const int kh = (int)h - (2 * (int)ho - 1);
+        const size_t o = po + (size_t)ho * a.Wo + j;
+        int i0 = kNoGrad;
+        float d0 = 0.0f;
+        if (live) { i0 = a.idx[o]; d0 = a.dy[o]; }
+        int i1 = __shfl_down(i0, 1);
+        float d1 = __shfl_down(d0, 1);
+        if (lane == 63u && has_right && live) { i1 = a.idx[o + 1]; d1 = a.dy[o + 1]; }
+        if (i0 == kh * 3 + 1) ga += d0;           // column 2j: the middle of window j
+        if (i0 == kh * 3 + 2) gb += d0;           // column 2j + 1: the right edge of window j, then the left edge of window j + 1
+        if (has_right && i1 == kh * 3 + 0) gb += d1;
+    }
+    if (!live) return;
+    const float s = a.scale[plane % a.C];
+    *reinterpret_cast<float2*>(a.dx + ((size_t)plane * a.H + h) * a.W + 2u * j) = make_float2(ga * s, gb * s);
 }
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -140,6 +273,45 @@ extern "C" int vita_channel_affine_relu_bwd_f32(const float* dy, const float* y,
     AffineBwdArgs a{dy, y, scale, dx, dres, (unsigned)(vec ? n / 4 : n), (unsigned)(vec ? HW / 4 : HW), (unsigned)C};
     if (vec) VITA_AFFINE_DISPATCH(channel_affine_bwd_v4_kernel, a);
     else VITA_AFFINE_DISPATCH(channel_affine_bwd_kernel, a);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+static int check_stem(const char* who, int64_t planes, int32_t C, int32_t H, int32_t W) {
+    VITA_REQUIRE(planes >= 0 && C >= 1 && H >= 1 && W >= 1 && planes % C == 0 && planes <= 65535,
+                 "%s: planes (%lld) must be a multiple of C (%d) and at most 65535 per call, H (%d), W (%d) >= 1", who, (long long)planes, C, H, W);
+    return VITA_OK;
+}
+
+extern "C" int vita_affine_relu_maxpool3s2_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, int64_t planes,
+                                               int32_t C, int32_t H, int32_t W, vita_stream_t stream) {
+    const char* who = "vita_affine_relu_maxpool3s2_f32";
+    VITA_TRY(check_stem(who, planes, C, H, W));
+    if (planes == 0) return VITA_OK;
+    VITA_REQUIRE(x && scale && shift && y && idx, "%s: null pointer", who);
+    const unsigned Ho = (unsigned)(H - 1) / 2u + 1u, Wo = (unsigned)(W - 1) / 2u + 1u;
+    StemArgs a{x, scale, shift, y, idx, (unsigned)planes, (unsigned)C, (unsigned)H, (unsigned)W, Ho, Wo};
+    const dim3 grid((Wo + 63u) / 64u, (Ho + 3u) / 4u, (unsigned)planes);
+    if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0) hipLaunchKernelGGL(stem_tail_even_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(stem_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+extern "C" int vita_affine_relu_maxpool3s2_bwd_f32(const float* dy, const uint8_t* idx, const float* scale, float* dx, int64_t planes, int32_t C,
+                                                   int32_t H, int32_t W, vita_stream_t stream) {
+    const char* who = "vita_affine_relu_maxpool3s2_bwd_f32";
+    VITA_TRY(check_stem(who, planes, C, H, W));
+    if (planes == 0) return VITA_OK;
+    VITA_REQUIRE(dy && idx && scale && dx, "%s: null pointer", who);
+    const unsigned Ho = (unsigned)(H - 1) / 2u + 1u, Wo = (unsigned)(W - 1) / 2u + 1u;
+    StemBwdArgs a{dy, idx, scale, dx, (unsigned)planes, (unsigned)C, (unsigned)H, (unsigned)W, Ho, Wo};
+    if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(dx) & 7u) == 0)
+        hipLaunchKernelGGL(stem_tail_bwd_even_kernel, dim3((Wo + 63u) / 64u, ((unsigned)H + 3u) / 4u, (unsigned)planes), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    else
+        hipLaunchKernelGGL(stem_tail_bwd_kernel, dim3(((unsigned)W + 63u) / 64u, ((unsigned)H + 3u) / 4u, (unsigned)planes), dim3(256), 0,
+                           (hipStream_t)stream, a);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }

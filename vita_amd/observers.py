@@ -4,8 +4,8 @@
 resize to `resize_shape`, ONE random crop per call (two torch.randint draws, training and evaluation alike), ResNet18 up to layer4
 with frozen batch-norm statistics, average pool, and `[state | camera features]` per row (or the tokenised form).  It is a torch
 module that plugs into `VitaPolicy(observer=...)`: its convolutions are MIOpen's; everything between them — frozen batch norm,
-shortcut add, ReLU — is one hand-written pass per convolution on the device (vita_channel_affine_relu_f32 and its backward,
-include/vita_hip.h; bitwise the unfused torch arithmetic, VITA_OBSERVER_TORCH_EPILOGUE=1 runs the torch ops instead; CPU tensors
+shortcut add, ReLU, and the stem's max pool — is one hand-written pass per convolution on the device (vita_channel_affine_relu_f32,
+vita_affine_relu_maxpool3s2_f32 and their backwards, include/vita_hip.h; bitwise the unfused torch arithmetic, VITA_OBSERVER_TORCH_EPILOGUE=1 runs the torch ops instead; CPU tensors
 always take the torch ops, which is how the module's logic is pinned against the reference in the build container).  Its
 output carries autograd, and the fused step returns d loss / d features (vita_compute_loss_f32's d_obs_features), so the
 backbone trains on the drop-in path as in the reference (vita_policy.py:222-229 puts it in the same AdamW group).
@@ -91,7 +91,12 @@ class ResNet18Backbone(nn.Module):
                 nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
 
     def forward(self, x):
-        x = self.maxpool(self.bn1(self.conv1(x), relu=True))
+        x = self.conv1(x)
+        if x.is_cuda and os.environ.get("VITA_OBSERVER_TORCH_EPILOGUE", "0") != "1":
+            from . import ops
+            x = ops.affine_relu_maxpool(x, *self.bn1.scale_shift())          # norm + ReLU + 3x3/2 max pool: one pass
+        else:
+            x = self.maxpool(self.bn1(x, relu=True))
         return {"feature_map": self.layer4(self.layer3(self.layer2(self.layer1(x))))}
 
 

@@ -618,6 +618,56 @@ def channel_affine_relu(x: Tensor, scale: Tensor, shift: Tensor, res: Optional[T
     return _ChannelAffineReLU.apply(x, res, scale, shift, relu)
 
 
+class _AffineReLUMaxPool(torch.autograd.Function):
+    """vita_affine_relu_maxpool3s2_f32 / _bwd_f32 (include/vita_hip.h)."""
+    MAX_PLANES = 65535
+
+    @staticmethod
+    def forward(ctx, x, scale, shift):
+        lib = L.load()
+        x = _f32(x, "affine_relu_maxpool: x").contiguous()
+        if x.dim() != 4 or scale.shape != (x.shape[1],) or shift.shape != scale.shape:
+            raise L.VitaHipError(f"affine_relu_maxpool: x {tuple(x.shape)} against scale {tuple(scale.shape)} / shift {tuple(shift.shape)}")
+        scale = _f32(scale, "affine_relu_maxpool: scale").contiguous()
+        shift = _f32(shift, "affine_relu_maxpool: shift").contiguous()
+        N, Cn, H, W = x.shape
+        if H < 1 or W < 1:
+            raise L.VitaHipError(f"affine_relu_maxpool: empty image {tuple(x.shape)}")
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, Cn, Ho, Wo), dtype=torch.float32, device=x.device)
+        idx = torch.empty((N, Cn, Ho, Wo), dtype=torch.uint8, device=x.device)
+        per = max(1, _AffineReLUMaxPool.MAX_PLANES // Cn)          # images per launch (grid z)
+        for n0 in range(0, N, per):
+            n1 = min(N, n0 + per)
+            L.check(lib.vita_affine_relu_maxpool3s2_f32(x[n0:n1].data_ptr(), scale.data_ptr(), shift.data_ptr(), y[n0:n1].data_ptr(),
+                                                        idx[n0:n1].data_ptr(), (n1 - n0) * Cn, Cn, H, W, _stream(x)),
+                    "vita_affine_relu_maxpool3s2_f32")
+        ctx.dims = (N, Cn, H, W, per)
+        ctx.save_for_backward(idx, scale)
+        ctx.mark_non_differentiable(idx)
+        return y, idx
+
+    @staticmethod
+    def backward(ctx, dy, _didx):
+        lib = L.load()
+        idx, scale = ctx.saved_tensors
+        N, Cn, H, W, per = ctx.dims
+        dy = _f32(dy, "affine_relu_maxpool: dy").contiguous()
+        dx = torch.empty((N, Cn, H, W), dtype=torch.float32, device=dy.device)
+        for n0 in range(0, N, per):
+            n1 = min(N, n0 + per)
+            L.check(lib.vita_affine_relu_maxpool3s2_bwd_f32(dy[n0:n1].data_ptr(), idx[n0:n1].data_ptr(), scale.data_ptr(), dx[n0:n1].data_ptr(),
+                                                            (n1 - n0) * Cn, Cn, H, W, _stream(dy)),
+                    "vita_affine_relu_maxpool3s2_bwd_f32")
+        return dx, None, None
+
+
+def affine_relu_maxpool(x: Tensor, scale: Tensor, shift: Tensor) -> Tensor:
+    """max_pool2d(relu(x * scale[c] + shift[c]), 3, 2, 1) over (N, C, H, W) in one pass, with its backward (the stem of the observer's
+    ResNet18, vita_amd/observers.py)."""
+    return _AffineReLUMaxPool.apply(x, scale, shift)[0]
+
+
 def normalize(x, mean, std): return _norm("vita_normalize_f32", x, mean, std)
 def unnormalize(x, mean, std): return _norm("vita_unnormalize_f32", x, mean, std)
 
