@@ -133,12 +133,14 @@ __global__ __launch_bounds__(256) void stem_tail_kernel(StemArgs a) {
 }
 
 __global__ __launch_bounds__(256) void stem_tail_even_kernel(StemArgs a) {
+    // lanes run over the plane's pooled outputs in row-major order: full waves whatever Wo is; a lane's left neighbour in the same
+    // output row holds the column it needs.  Every lane executes every exchange (no divergent exits before them).
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned wo = blockIdx.x * 64u + lane;
-    const unsigned ho = blockIdx.y * 4u + (threadIdx.x >> 6);
-    const unsigned plane = blockIdx.z;
-    if (ho >= a.Ho) return;                       // uniform over the wave: the lanes below exchange columns
-    const bool live = wo < a.Wo, has_left = wo > 0;
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    const unsigned plane = blockIdx.y;
+    const bool live = p < a.Ho * a.Wo;
+    const unsigned ho = live ? p / a.Wo : 0u, wo = live ? p - ho * a.Wo : 0u;
+    const bool has_left = wo > 0;
     const unsigned c = plane % a.C;
     const float s = a.scale[c], b = a.shift[c];
     const float* xp = a.x + (size_t)plane * a.H * a.W;
@@ -147,20 +149,22 @@ __global__ __launch_bounds__(256) void stem_tail_even_kernel(StemArgs a) {
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int h = (int)(2u * ho) - 1 + kh;
-        if (h < 0 || h >= (int)a.H) continue;
-        const float* row = xp + (size_t)h * a.W;
+        const bool ok = live && h >= 0 && h < (int)a.H;
+        const float* row = xp + (size_t)(ok ? h : 0) * a.W;
         float2 v = make_float2(0.0f, 0.0f);
-        if (live) v = *reinterpret_cast<const float2*>(row + 2u * wo);
+        if (ok) v = *reinterpret_cast<const float2*>(row + 2u * wo);
         v.x = relu_nan(v.x * s + b);
         v.y = relu_nan(v.y * s + b);
         float left = __shfl_up(v.y, 1);
-        if (lane == 0 && has_left && live) left = relu_nan(row[2u * wo - 1u] * s + b);
-        if (has_left) VITA_POOL_UPDATE(left, kh * 3 + 0);
-        VITA_POOL_UPDATE(v.x, kh * 3 + 1);
-        VITA_POOL_UPDATE(v.y, kh * 3 + 2);
+        if (lane == 0 && ok && has_left) left = relu_nan(row[2u * wo - 1u] * s + b);
+        if (ok) {
+            if (has_left) VITA_POOL_UPDATE(left, kh * 3 + 0);
+            VITA_POOL_UPDATE(v.x, kh * 3 + 1);
+            VITA_POOL_UPDATE(v.y, kh * 3 + 2);
+        }
     }
     if (!live) return;
-    const size_t o = ((size_t)plane * a.Ho + ho) * a.Wo + wo;
+    const size_t o = (size_t)plane * a.Ho * a.Wo + p;
     a.y[o] = best;
     a.idx[o] = best <= 0.0f ? kNoGrad : (unsigned char)arg;
 }
@@ -194,29 +198,33 @@ __global__ __launch_bounds__(256) void stem_tail_bwd_kernel(StemBwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void stem_tail_bwd_even_kernel(StemBwdArgs a) {
+    // lanes run over (h, j) in row-major order, j = a column pair (2j, 2j + 1); the right neighbour holds window j + 1
     const unsigned lane = threadIdx.x & 63u;
-    const unsigned j = blockIdx.x * 64u + lane;            // columns 2j, 2j + 1
-    const unsigned h = blockIdx.y * 4u + (threadIdx.x >> 6);
-    const unsigned plane = blockIdx.z;
-    if (h >= a.H) return;                         // uniform over the wave
-    const bool live = j < a.Wo, has_right = j + 1u < a.Wo;
+    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    const unsigned plane = blockIdx.y;
+    const bool live = p < a.H * a.Wo;
+    const unsigned h = live ? p / a.Wo : 0u, j = live ? p - h * a.Wo : 0u;
+    const bool has_right = j + 1u < a.Wo;
     const size_t po = (size_t)plane * a.Ho * a.Wo;
     float ga = 0.0f, gb = 0.0f;
     const unsigned ho0 = h / 2u, nwin = (h & 1u) ? 2u : 1u;
-    for (unsigned t = 0; t < nwin; ++t) {
+#pragma unroll
+    for (unsigned t = 0; t < 2u; ++t) {
         const unsigned ho = ho0 + t;
-        if (ho >= a.Ho) break;
+        const bool ok = live && t < nwin && ho < a.Ho;
         const int kh = (int)h - (2 * (int)ho - 1);
-        const size_t o = po + (size_t)ho * a.Wo + j;
+        const size_t o = po + (size_t)(ok ? ho : 0u) * a.Wo + j;
         int i0 = kNoGrad;
         float d0 = 0.0f;
-        if (live) { i0 = a.idx[o]; d0 = a.dy[o]; }
+        if (ok) { i0 = a.idx[o]; d0 = a.dy[o]; }
         int i1 = __shfl_down(i0, 1);
         float d1 = __shfl_down(d0, 1);
-        if (lane == 63u && has_right && live) { i1 = a.idx[o + 1]; d1 = a.dy[o + 1]; }
-        if (i0 == kh * 3 + 1) ga += d0;           // column 2j: the middle of window j
-        if (i0 == kh * 3 + 2) gb += d0;           // column 2j + 1: the right edge of window j, then the left edge of window j + 1
-        if (has_right && i1 == kh * 3 + 0) gb += d1;
+        if (lane == 63u && ok && has_right) { i1 = a.idx[o + 1]; d1 = a.dy[o + 1]; }
+        if (ok) {
+            if (i0 == kh * 3 + 1) ga += d0;           // column 2j: the middle of window j
+            if (i0 == kh * 3 + 2) gb += d0;           // column 2j + 1: the right edge of window j, then the left edge of window j + 1
+            if (has_right && i1 == kh * 3 + 0) gb += d1;
+        }
     }
     if (!live) return;
     const float s = a.scale[plane % a.C];
@@ -292,7 +300,8 @@ extern "C" int vita_affine_relu_maxpool3s2_f32(const float* x, const float* scal
     const unsigned Ho = (unsigned)(H - 1) / 2u + 1u, Wo = (unsigned)(W - 1) / 2u + 1u;
     StemArgs a{x, scale, shift, y, idx, (unsigned)planes, (unsigned)C, (unsigned)H, (unsigned)W, Ho, Wo};
     const dim3 grid((Wo + 63u) / 64u, (Ho + 3u) / 4u, (unsigned)planes);
-    if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0) hipLaunchKernelGGL(stem_tail_even_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(x) & 7u) == 0)
+        hipLaunchKernelGGL(stem_tail_even_kernel, dim3((Ho * Wo + 255u) / 256u, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(stem_tail_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
@@ -307,8 +316,7 @@ extern "C" int vita_affine_relu_maxpool3s2_bwd_f32(const float* dy, const uint8_
     const unsigned Ho = (unsigned)(H - 1) / 2u + 1u, Wo = (unsigned)(W - 1) / 2u + 1u;
     StemBwdArgs a{dy, idx, scale, dx, (unsigned)planes, (unsigned)C, (unsigned)H, (unsigned)W, Ho, Wo};
     if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(dx) & 7u) == 0)
-        hipLaunchKernelGGL(stem_tail_bwd_even_kernel, dim3((Wo + 63u) / 64u, ((unsigned)H + 3u) / 4u, (unsigned)planes), dim3(256), 0,
-                           (hipStream_t)stream, a);
+        hipLaunchKernelGGL(stem_tail_bwd_even_kernel, dim3(((unsigned)H * Wo + 255u) / 256u, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(stem_tail_bwd_kernel, dim3(((unsigned)W + 63u) / 64u, ((unsigned)H + 3u) / 4u, (unsigned)planes), dim3(256), 0,
                            (hipStream_t)stream, a);
