@@ -441,6 +441,19 @@ def main():
             hbm[name] = {"avg_us": round(dt_ * 1e6, 2), "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / dt_ / 1e9, 1),
                          "frac_of_hbm_peak": round(nbytes / dt_ / 8e12, 4)}
         del xa, xb, hh, dyh, pp, gg, mm, vv, ee
+        # the observer's elementwise tail at the stem's shape for 64 frames of 224 x 308 (csrc/vita_observer.hip)
+        sx = torch.randn(64, 64, 112, 154, device=dev)
+        ssc, ssh = torch.rand(64, device=dev) + 0.5, torch.randn(64, device=dev) * 0.1
+        n_el = sx.numel()
+        with torch.no_grad():
+            for name, fn, nbytes in (
+                    ("observer frozen-norm + ReLU 64x64x112x154", lambda: ops.channel_affine_relu(sx, ssc, ssh, None, True), 8 * n_el),
+                    ("observer frozen-norm + ReLU + maxpool3s2 64x64x112x154 (in + pooled out + 1 B/window)",
+                     lambda: ops.affine_relu_maxpool(sx, ssc, ssh), 4 * n_el + 5 * (n_el // 4))):
+                dt_ = time_op(fn)
+                hbm[name] = {"avg_us": round(dt_ * 1e6, 2), "algorithmic_bytes": nbytes, "GB_per_s": round(nbytes / dt_ / 1e9, 1),
+                             "frac_of_hbm_peak": round(nbytes / dt_ / 8e12, 4)}
+        del sx
 
     # HBM bytes per fc1 launch from the PMC passes (tools/profile.sh -> profiles/traffic.json): a committed measurement, not
     # taken in this run, so it is reported only for the shape it was taken on, with its source named
