@@ -103,3 +103,41 @@ def test_a_device_batch_trains_the_policy():
     loss, metrics = pol.forward(batch)
     loss.backward()
     assert torch.isfinite(loss) and pol.obs_encoder.weight.grad is not None and "flow_loss" in metrics
+
+
+def test_frames_from_the_replay_buffer_train_the_policy_through_the_observer():
+    """uint8 frames resident in HBM -> one gather launch (float32 / 255, channels first) -> normalise -> ResNet18 observer -> the fused
+    step; three optimizer steps of the drop-in trainer loop (policy_trainer.py:76-94) move the backbone and lower the loss."""
+    cfg = default_config("pusht")
+    cfg.policy.flow_matcher.name = "conditional"
+    S, A, cam = cfg.task.state_dim, cfg.task.action_dim, cfg.task.image_keys[0]
+    stats = {cfg.task.state_key: {"mean": [0.0] * S, "std": [1.0] * S}, cfg.task.action_key: {"mean": [0.0] * A, "std": [1.0] * A},
+             cam: {"mean": [[[0.5]], [[0.5]], [[0.5]]], "std": [[[0.25]], [[0.25]], [[0.25]]]}}
+    torch.manual_seed(0)
+    pol = VitaPolicy(cfg, stats, observer="resnet18").to(DEV)
+    rng = np.random.default_rng(1)
+    lengths = [30, 26]
+    N = sum(lengths)
+    arrays = {cfg.task.state_key: rng.standard_normal((N, S)).astype(np.float32),
+              cam: rng.integers(0, 256, (N, 96, 96, 3), dtype=np.uint8),
+              cfg.task.action_key: rng.standard_normal((N, A)).astype(np.float32)}
+    dts = {k: v for k, v in policy_delta_timestamps(pol, cfg.task).items() if k in arrays}
+    assert cam in dts
+    ds = DeviceReplayDataset(arrays, lengths, dts, cfg.task.fps, image_keys=(cam,), device=DEV)
+    loader = DeviceBatchLoader(ds, batch_size=16, drop_n_last_frames=8, is_training=True)
+    batch = next(iter(loader))
+    assert tuple(batch[cam].shape) == (16, 1, 3, 96, 96) and batch[cam].dtype == torch.float32 and float(batch[cam].max()) <= 1.0
+    pol.train()
+    opt = pol.get_optimizer()
+    w0 = pol.observer.backbone.conv1.weight.detach().clone()
+    first = None
+    for _ in range(3):
+        opt.zero_grad()
+        torch.manual_seed(5)                       # same crop and same draws: the loss on this batch must go down
+        loss, _ = pol.forward(batch)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(pol.parameters(), cfg.train.grad_clip_norm)
+        opt.step()
+        first = loss.item() if first is None else first
+    assert torch.isfinite(loss) and loss.item() < first
+    assert not torch.equal(w0, pol.observer.backbone.conv1.weight)

@@ -114,6 +114,15 @@ def test_train_step_through_the_backbone():
     assert nerr(leaf.grad, f64.grad) <= 2e-5
 
 
+def test_native_trainer_refuses_a_trainable_observer_loudly():
+    cfg = _cfg()
+    pol = _policy(cfg)
+    pol.train()
+    nb = pol.normalize_targets(pol.normalize_inputs(_batch(cfg, 4)))
+    with pytest.raises(NotImplementedError, match="trainable observer"):
+        pol.loss_and_grads(nb)
+
+
 def test_generate_and_select_action_from_frames():
     cfg = _cfg()
     pol = _policy(cfg)

@@ -671,6 +671,10 @@ class VitaPolicy(nn.Module):
             raise NotImplementedError("the native trainer (flat buffers, fused optimizer) has no external action encoder / decoder "
                                       "(transformer, cnn): train it through compute_loss(...).backward() with a torch optimizer (the drop-in path)")
         obs_features = self.observer(batch)
+        if obs_features.requires_grad:
+            raise NotImplementedError("the native trainer (flat buffers, fused optimizer) does not carry gradients into a trainable observer "
+                                      "(observer='resnet18'): train it through compute_loss(...).backward() with policy.get_optimizer() (the "
+                                      "drop-in path), or run the observer under torch.no_grad() to keep it fixed")
         actions = batch[self.config.task.action_key]
         pw, gw, gsd = self._train_handles()
         if self._flat_grad is None:
