@@ -78,3 +78,38 @@ def test_load_torchvision_state_dict_ignores_head():
     sd["fc.weight"], sd["fc.bias"], sd["bn1.num_batches_tracked"] = torch.zeros(1000, 512), torch.zeros(1000), torch.tensor(0)
     obs.load_backbone_state_dict(sd)
     assert float(obs.backbone.layer3[1].bn2.running_var[0]) == 0.5
+
+
+def test_backbone_against_an_independent_resnet18():
+    """torchvision is absent, so the ResNet18 definition cannot be pinned to it; `transformers` ships an independent implementation of the
+    same network (ResNetModel with basic layers — the class torchvision's resnet18 weights are converted into as microsoft/resnet-18).
+    With the same tensors, in eval mode (BatchNorm on running statistics == FrozenBatchNorm2d), both must give the same layer4 map."""
+    tr = pytest.importorskip("transformers")
+    cfg = tr.ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[64, 128, 256, 512], depths=[2, 2, 2, 2], layer_type="basic",
+                          hidden_act="relu", downsample_in_first_stage=False)
+    ref = tr.ResNetModel(cfg).eval()
+    bb = seeded_backbone()
+    sd = bb.state_dict()
+
+    def put(conv_layer, conv_key, bn_key):
+        conv_layer.convolution.weight.data.copy_(sd[conv_key + ".weight"])
+        for name in ("weight", "bias", "running_mean", "running_var"):
+            getattr(conv_layer.normalization, name).data.copy_(sd[f"{bn_key}.{name}"])
+
+    put(ref.embedder.embedder, "conv1", "bn1")
+    for i, stage in enumerate(ref.encoder.stages):
+        for j, layer in enumerate(stage.layers):
+            pre = f"layer{i + 1}.{j}"
+            put(layer.layer[0], pre + ".conv1", pre + ".bn1")
+            put(layer.layer[1], pre + ".conv2", pre + ".bn2")
+            if pre + ".downsample.0.weight" in sd:
+                put(layer.shortcut, pre + ".downsample.0", pre + ".downsample.1")
+            else:
+                assert not hasattr(layer.shortcut, "convolution")
+    assert sum(p.numel() for n, p in ref.named_parameters() if "normalization" not in n) == sum(p.numel() for p in bb.parameters())
+    x = torch.rand(2, 3, 84, 100, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        want = ref(x).last_hidden_state
+        got = bb(x)["feature_map"]
+    assert got.shape == want.shape == (2, 512, 3, 4)
+    torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-5)

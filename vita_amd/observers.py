@@ -12,7 +12,8 @@ backbone trains on the drop-in path as in the reference (vita_policy.py:222-229 
 
 Parity: the observer's own logic (image stacking / resize / crop / pooling / concatenation / tokenisation) is pinned by running the
 reference's BaseObserver.get_images and ResNetObserver._observe_* around this file's backbone (tests/golden/observer.safetensors).
-The ResNet18 definition itself and FrozenBatchNorm2d restate torchvision (absent from this image): UNPINNED.  Parameter and buffer
+The ResNet18 definition itself and FrozenBatchNorm2d restate torchvision (absent from this image): UNPINNED against it, cross-checked
+against transformers' independent ResNetModel (basic layers) on the same tensors (tests/test_observers_cpu.py).  Parameter and buffer
 names are torchvision's behind `backbone.`, so a reference checkpoint's `observer.*` tensors load; ImageNet weights are not
 downloaded here — pass a local torchvision state dict to `load_backbone_state_dict`."""
 from __future__ import annotations
