@@ -96,8 +96,8 @@ __global__ __launch_bounds__(256) void channel_affine_bwd_kernel(AffineBwdArgs a
 // A window whose maximum is <= 0 passes no gradient through the ReLU: its byte says so (kNoGrad).
 // Backward therefore needs neither the convolution's output nor any activation: a pixel receives dy of every window it won.
 // Sums run over windows in (row, column) order, as torch's max_pool2d backward does.
-// Even W (the reference's crops: 308, 224, 84): a lane holds two adjacent columns (float2 loads and stores, whole cache lines) and
-// gets the third from its neighbour lane; odd W takes the one-element-per-lane kernels.
+// Even W (the reference's crops: 308, 224, 84): a lane holds two adjacent columns (float2 loads and stores, whole cache lines) plus the
+// column to their left (an L1 hit: the neighbour lane's); odd W takes the one-element-per-lane kernels.
 constexpr unsigned char kNoGrad = 255;
 #define VITA_POOL_UPDATE(v, k) do { const float v__ = (v); if (arg < 0 || v__ > best || v__ != v__) { best = v__; arg = (k); } } while (0)
 struct StemArgs {
@@ -133,38 +133,41 @@ __global__ __launch_bounds__(256) void stem_tail_kernel(StemArgs a) {
 }
 
 __global__ __launch_bounds__(256) void stem_tail_even_kernel(StemArgs a) {
-    // lanes run over the plane's pooled outputs in row-major order: full waves whatever Wo is; a lane's left neighbour in the same
-    // output row holds the column it needs.  Every lane executes every exchange (no divergent exits before them).
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    // lanes run over the plane's pooled outputs in row-major order: full waves whatever Wo is.  All six loads of a lane (a float2 and
+    // its left neighbour on three rows) are unconditional on clamped addresses, so they are in flight together; validity is applied
+    // when the window is scanned.
+    const unsigned total = a.Ho * a.Wo;
+    const unsigned p0 = blockIdx.x * 256u + threadIdx.x;
     const unsigned plane = blockIdx.y;
-    const bool live = p < a.Ho * a.Wo;
-    const unsigned ho = live ? p / a.Wo : 0u, wo = live ? p - ho * a.Wo : 0u;
+    const bool live = p0 < total;
+    const unsigned p = live ? p0 : total - 1u;
+    const unsigned ho = p / a.Wo, wo = p - ho * a.Wo;
     const bool has_left = wo > 0;
     const unsigned c = plane % a.C;
     const float s = a.scale[c], b = a.shift[c];
     const float* xp = a.x + (size_t)plane * a.H * a.W;
+    float2 v[3];
+    float l[3];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = (int)(2u * ho) - 1 + kh;
+        const int hc = h < 0 ? 0 : (h >= (int)a.H ? (int)a.H - 1 : h);
+        const float* row = xp + (size_t)hc * a.W + 2u * wo;
+        v[kh] = *reinterpret_cast<const float2*>(row);
+        l[kh] = *(row - (has_left ? 1 : 0));
+    }
     float best = -INFINITY;
     int arg = -1;
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int h = (int)(2u * ho) - 1 + kh;
-        const bool ok = live && h >= 0 && h < (int)a.H;
-        const float* row = xp + (size_t)(ok ? h : 0) * a.W;
-        float2 v = make_float2(0.0f, 0.0f);
-        if (ok) v = *reinterpret_cast<const float2*>(row + 2u * wo);
-        v.x = relu_nan(v.x * s + b);
-        v.y = relu_nan(v.y * s + b);
-        float left = __shfl_up(v.y, 1);
-        if (lane == 0 && ok && has_left) left = relu_nan(row[2u * wo - 1u] * s + b);
-        if (ok) {
-            if (has_left) VITA_POOL_UPDATE(left, kh * 3 + 0);
-            VITA_POOL_UPDATE(v.x, kh * 3 + 1);
-            VITA_POOL_UPDATE(v.y, kh * 3 + 2);
-        }
+        if (h < 0 || h >= (int)a.H) continue;
+        if (has_left) VITA_POOL_UPDATE(relu_nan(l[kh] * s + b), kh * 3 + 0);
+        VITA_POOL_UPDATE(relu_nan(v[kh].x * s + b), kh * 3 + 1);
+        VITA_POOL_UPDATE(relu_nan(v[kh].y * s + b), kh * 3 + 2);
     }
     if (!live) return;
-    const size_t o = (size_t)plane * a.Ho * a.Wo + p;
+    const size_t o = (size_t)plane * total + p;
     a.y[o] = best;
     a.idx[o] = best <= 0.0f ? kNoGrad : (unsigned char)arg;
 }
@@ -198,33 +201,36 @@ __global__ __launch_bounds__(256) void stem_tail_bwd_kernel(StemBwdArgs a) {
 }
 
 __global__ __launch_bounds__(256) void stem_tail_bwd_even_kernel(StemBwdArgs a) {
-    // lanes run over (h, j) in row-major order, j = a column pair (2j, 2j + 1); the right neighbour holds window j + 1
-    const unsigned lane = threadIdx.x & 63u;
-    const unsigned p = blockIdx.x * 256u + threadIdx.x;
+    // lanes run over (h, j) in row-major order, j = a column pair (2j, 2j + 1).  The (up to) two window rows x two windows a lane looks
+    // at are loaded unconditionally on clamped addresses (eight loads in flight), validity is applied when they are summed.
+    const unsigned total = a.H * a.Wo;
+    const unsigned p0 = blockIdx.x * 256u + threadIdx.x;
     const unsigned plane = blockIdx.y;
-    const bool live = p < a.H * a.Wo;
-    const unsigned h = live ? p / a.Wo : 0u, j = live ? p - h * a.Wo : 0u;
+    const bool live = p0 < total;
+    const unsigned p = live ? p0 : total - 1u;
+    const unsigned h = p / a.Wo, j = p - h * a.Wo;
     const bool has_right = j + 1u < a.Wo;
     const size_t po = (size_t)plane * a.Ho * a.Wo;
-    float ga = 0.0f, gb = 0.0f;
     const unsigned ho0 = h / 2u, nwin = (h & 1u) ? 2u : 1u;
+    int i0[2], i1[2];
+    float d0[2], d1[2];
+#pragma unroll
+    for (unsigned t = 0; t < 2u; ++t) {
+        const unsigned ho = ho0 + t < a.Ho ? ho0 + t : a.Ho - 1u;
+        const size_t o = po + (size_t)ho * a.Wo + j;
+        const size_t o1 = o + (has_right ? 1u : 0u);
+        i0[t] = a.idx[o]; d0[t] = a.dy[o];
+        i1[t] = a.idx[o1]; d1[t] = a.dy[o1];
+    }
+    float ga = 0.0f, gb = 0.0f;
 #pragma unroll
     for (unsigned t = 0; t < 2u; ++t) {
         const unsigned ho = ho0 + t;
-        const bool ok = live && t < nwin && ho < a.Ho;
+        if (t >= nwin || ho >= a.Ho) continue;
         const int kh = (int)h - (2 * (int)ho - 1);
-        const size_t o = po + (size_t)(ok ? ho : 0u) * a.Wo + j;
-        int i0 = kNoGrad;
-        float d0 = 0.0f;
-        if (ok) { i0 = a.idx[o]; d0 = a.dy[o]; }
-        int i1 = __shfl_down(i0, 1);
-        float d1 = __shfl_down(d0, 1);
-        if (lane == 63u && ok && has_right) { i1 = a.idx[o + 1]; d1 = a.dy[o + 1]; }
-        if (ok) {
-            if (i0 == kh * 3 + 1) ga += d0;           // column 2j: the middle of window j
-            if (i0 == kh * 3 + 2) gb += d0;           // column 2j + 1: the right edge of window j, then the left edge of window j + 1
-            if (has_right && i1 == kh * 3 + 0) gb += d1;
-        }
+        if (i0[t] == kh * 3 + 1) ga += d0[t];           // column 2j: the middle of window j
+        if (i0[t] == kh * 3 + 2) gb += d0[t];           // column 2j + 1: the right edge of window j, then the left edge of window j + 1
+        if (has_right && i1[t] == kh * 3 + 0) gb += d1[t];
     }
     if (!live) return;
     const float s = a.scale[plane % a.C];
