@@ -587,6 +587,9 @@ class _ChannelAffineReLU(torch.autograd.Function):
                 raise L.VitaHipError(f"channel_affine_relu: shortcut {tuple(res.shape)} against x {tuple(x.shape)}")
         scale = _f32(scale, "channel_affine_relu: scale").contiguous()
         shift = _f32(shift, "channel_affine_relu: shift").contiguous()
+        for name, t in (("scale", scale), ("shift", shift), ("shortcut", res)):
+            if t is not None and t.device != x.device:
+                raise L.VitaHipError(f"channel_affine_relu: {name} is on {t.device}, x on {x.device}")
         Cn = x.shape[1]
         hw = 1
         for d in x.shape[2:]:
@@ -630,6 +633,8 @@ class _AffineReLUMaxPool(torch.autograd.Function):
             raise L.VitaHipError(f"affine_relu_maxpool: x {tuple(x.shape)} against scale {tuple(scale.shape)} / shift {tuple(shift.shape)}")
         scale = _f32(scale, "affine_relu_maxpool: scale").contiguous()
         shift = _f32(shift, "affine_relu_maxpool: shift").contiguous()
+        if scale.device != x.device or shift.device != x.device:
+            raise L.VitaHipError(f"affine_relu_maxpool: scale / shift on {scale.device} / {shift.device}, x on {x.device}")
         N, Cn, H, W = x.shape
         if H < 1 or W < 1:
             raise L.VitaHipError(f"affine_relu_maxpool: empty image {tuple(x.shape)}")
