@@ -206,7 +206,8 @@ def test_backbone_with_the_fused_tail_equals_the_torch_ops(monkeypatch):
         assert nerr(outs["0"][1][k], outs["1"][1][k]) <= 1e-4, k      # MIOpen's weight-gradient reductions are not run-to-run bitwise
 
 
-@pytest.mark.parametrize("shape", [(2, 3, 9, 11), (3, 8, 42, 42), (1, 64, 112, 154), (2, 4, 1, 1), (2, 5, 2, 7), (0, 4, 6, 6)])
+@pytest.mark.parametrize("shape", [(2, 3, 9, 11), (3, 8, 42, 42), (1, 64, 112, 154), (2, 4, 1, 1), (2, 5, 2, 7), (0, 4, 6, 6),
+                                   (2, 16, 112, 112), (3, 2, 7, 4), (1, 3, 5, 8)])      # widths divisible by four: the four-column backward
 def test_stem_tail_is_bitwise_norm_relu_maxpool(shape):
     from vita_amd import ops
     import torch.nn.functional as F

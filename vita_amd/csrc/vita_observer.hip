@@ -237,6 +237,49 @@ __global__ __launch_bounds__(256) void stem_tail_bwd_even_kernel(StemBwdArgs a) 
     *reinterpret_cast<float2*>(a.dx + ((size_t)plane * a.H + h) * a.W + 2u * j) = make_float2(ga * s, gb * s);
 }
 
+__global__ __launch_bounds__(256) void stem_tail_bwd_quad_kernel(StemBwdArgs a) {
+    // W % 4 == 0: a lane owns four columns 4q .. 4q + 3 of row h (one float4 store) and looks at windows 2q, 2q + 1, 2q + 2 of the one
+    // or two window rows over h: per window row one 2-byte and one 1-byte index load, one float2 and one float dy load.
+    const unsigned Q = a.W / 4u;
+    const unsigned total = a.H * Q;
+    const unsigned p0 = blockIdx.x * 256u + threadIdx.x;
+    const unsigned plane = blockIdx.y;
+    const bool live = p0 < total;
+    const unsigned p = live ? p0 : total - 1u;
+    const unsigned h = p / Q, q = p - h * Q;
+    const bool has_right = q + 1u < Q;                 // window 2q + 2 exists
+    const size_t po = (size_t)plane * a.Ho * a.Wo;
+    const unsigned ho0 = h / 2u, nwin = (h & 1u) ? 2u : 1u;
+    int ia[2], ib[2], ic[2];
+    float da[2], db[2], dc[2];
+#pragma unroll
+    for (unsigned t = 0; t < 2u; ++t) {
+        const unsigned ho = ho0 + t < a.Ho ? ho0 + t : a.Ho - 1u;
+        const size_t o = po + (size_t)ho * a.Wo + 2u * q;
+        const size_t oc = o + (has_right ? 2u : 0u);
+        const unsigned short two = *reinterpret_cast<const unsigned short*>(a.idx + o);
+        const float2 d = *reinterpret_cast<const float2*>(a.dy + o);
+        ia[t] = two & 0xff; ib[t] = two >> 8; ic[t] = a.idx[oc];
+        da[t] = d.x; db[t] = d.y; dc[t] = a.dy[oc];
+    }
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+#pragma unroll
+    for (unsigned t = 0; t < 2u; ++t) {
+        const unsigned ho = ho0 + t;
+        if (t >= nwin || ho >= a.Ho) continue;
+        const int k = ((int)h - (2 * (int)ho - 1)) * 3;
+        if (ia[t] == k + 1) g0 += da[t];                      // column 4q: the middle of window 2q
+        if (ia[t] == k + 2) g1 += da[t];                      // column 4q + 1: right edge of window 2q, then left edge of window 2q + 1
+        if (ib[t] == k + 0) g1 += db[t];
+        if (ib[t] == k + 1) g2 += db[t];                      // column 4q + 2: the middle of window 2q + 1
+        if (ib[t] == k + 2) g3 += db[t];                      // column 4q + 3: right edge of window 2q + 1, then left edge of window 2q + 2
+        if (has_right && ic[t] == k + 0) g3 += dc[t];
+    }
+    if (!live) return;
+    const float s = a.scale[plane % a.C];
+    *reinterpret_cast<float4*>(a.dx + ((size_t)plane * a.H + h) * a.W + 4u * q) = make_float4(g0 * s, g1 * s, g2 * s, g3 * s);
+}
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define VITA_AFFINE_DISPATCH(KERNEL, ARGS)                                                                                   \
@@ -321,7 +364,11 @@ extern "C" int vita_affine_relu_maxpool3s2_bwd_f32(const float* dy, const uint8_
     VITA_REQUIRE(dy && idx && scale && dx, "%s: null pointer", who);
     const unsigned Ho = (unsigned)(H - 1) / 2u + 1u, Wo = (unsigned)(W - 1) / 2u + 1u;
     StemBwdArgs a{dy, idx, scale, dx, (unsigned)planes, (unsigned)C, (unsigned)H, (unsigned)W, Ho, Wo};
-    if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(dx) & 7u) == 0)
+    if (W % 4 == 0 && (reinterpret_cast<uintptr_t>(dx) & 15u) == 0 && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0 &&
+        (reinterpret_cast<uintptr_t>(idx) & 1u) == 0)
+        hipLaunchKernelGGL(stem_tail_bwd_quad_kernel, dim3(((unsigned)H * ((unsigned)W / 4u) + 255u) / 256u, (unsigned)planes), dim3(256), 0,
+                           (hipStream_t)stream, a);
+    else if (W % 2 == 0 && (reinterpret_cast<uintptr_t>(dx) & 7u) == 0)
         hipLaunchKernelGGL(stem_tail_bwd_even_kernel, dim3(((unsigned)H * Wo + 255u) / 256u, (unsigned)planes), dim3(256), 0, (hipStream_t)stream, a);
     else
         hipLaunchKernelGGL(stem_tail_bwd_kernel, dim3(((unsigned)W + 63u) / 64u, ((unsigned)H + 3u) / 4u, (unsigned)planes), dim3(256), 0,
