@@ -25,7 +25,8 @@ def timed(fn, n=20, w=3):
 
 
 def main():
-    x = torch.randn(128, 64, 112, 154, device=DEV, requires_grad=True)
+    W = int(os.environ.get("STEM_W", "154"))           # 154: hook_package (308-wide crops); 112: the 224-pixel crops
+    x = torch.randn(128, 64, 112, W, device=DEV, requires_grad=True)
     sc, sh = torch.rand(64, device=DEV) + 0.5, torch.randn(64, device=DEV) * 0.1
     n = x.numel()
     with torch.no_grad():
@@ -34,7 +35,7 @@ def main():
     dy = torch.randn_like(y)
     b = timed(lambda: torch.autograd.grad(y, x, dy, retain_graph=True))
     nb = 4 * n + 5 * (n // 4)
-    print(json.dumps({"fwd_ms": round(f, 4), "fwd_GBps": round(nb / f / 1e6, 1), "bwd_ms": round(b, 4), "bwd_GBps": round(nb / b / 1e6, 1)}))
+    print(json.dumps({"W": W, "fwd_ms": round(f, 4), "fwd_GBps": round(nb / f / 1e6, 1), "bwd_ms": round(b, 4), "bwd_GBps": round(nb / b / 1e6, 1)}))
 
 
 if __name__ == "__main__":
