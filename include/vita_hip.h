@@ -162,6 +162,10 @@ int vita_ode_sample_f32(const vita_flownet_weights* w, const float* x0, int64_t 
  * (*status - 1) and x_out is NOT valid (cannot happen while the launch's <= 256 workgroups are resident; the bound only
  * guarantees that the kernel always ends).  VITA_NO_PERSISTENT=1 in the environment selects the per-launch path. */
 int vita_ode_sample_status(const vita_flownet_weights* w, int32_t B, int32_t num_steps, const void* workspace, int32_t* status);
+/* A timed-out solve cannot be missed (round 3): behind every in-launch sampler the library enqueues a one-pass kernel that reads
+ * the same status word and, when it is set, overwrites x_out / traj / the fused decoder's actions with NaN -- so the failure travels
+ * with the data and needs no host synchronisation to be seen; the decoder that runs behind a poisoned solve yields NaN actions.
+ * VitaPolicy.select_action / validate also read the word and raise (vita_amd/policy.py). */
 /* the same word for the workspace of vita_generate_actions_f32 (its solve runs in one launch at serving batches, B <= 64, and at
  * chip-filling ones): != 0 means that call's actions are NOT valid */
 int vita_generate_actions_status(const vita_flownet_weights* fw, int32_t B, int32_t num_steps, const void* workspace, int32_t* status);
@@ -173,6 +177,9 @@ int vita_ode_sample_takes_persistent(const vita_flownet_weights* w, int32_t B);
 /* diagnostic: NULL (default), or a device buffer of 256 * num_steps * (2 + 2L) * 6 uint64 that the persistent launches of this
  * process fill with 100 MHz clock stamps per workgroup and phase: phase start, wait over, tiles done, published, then the shader clock at start and publish (tools/persistent_stamps.py) */
 int vita_debug_ode_stamps(void* device_buf);
+/* diagnostic (tests/test_gpu_timeout.py): the bound of every hand-off spin of the in-launch samplers, in polls; 0 restores the
+ * default (1 << 22, seconds).  A tiny bound forces the time-out path: status != 0 and NaN outputs. */
+int vita_debug_set_spin_limit(uint32_t spins);
 
 /* ---------------------------------------------------------------------------------------
  * vita_decoder_forward_f32 — SimpleActionDecoder.forward (action_ae.py:267-279):
@@ -222,6 +229,9 @@ int vita_generate_actions_noalloc_f32(const float* obs_w, const float* obs_b, in
                                       const vita_flownet_weights* fw, const vita_decoder_weights* dw,
                                       const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
                                       float* latents_out, int32_t B, int32_t num_steps, vita_stream_t stream);
+/* vita_generate_actions_status for the built-in array on the current device (the caller never sees its address); SYNCHRONISES
+ * (a blocking 4-byte copy).  No counterpart in the reference. */
+int vita_generate_actions_noalloc_status(const vita_flownet_weights* fw, int32_t B, int32_t num_steps, int32_t* status);
 
 /* ---------------------------------------------------------------------------------------
  * Loss kernels (HBM-bound elementwise + two-stage deterministic reduction).
@@ -525,6 +535,9 @@ int vita_generate_actions_bf16(const float* obs_b, int32_t O, const vita_flownet
                                const vita_bf16_weights* bw, const float* obs_features, int64_t ldobs, float* actions, int64_t lda,
                                float* latents_out, int32_t B, int32_t num_steps, void* workspace, size_t workspace_bytes,
                                vita_stream_t stream);
+/* the status word of that call's in-launch sampler (vita_ode_sample_status); SYNCHRONISES */
+int vita_generate_actions_bf16_status(const vita_flownet_weights* fw, int32_t O, int32_t B, int32_t num_steps, const void* workspace,
+                                      int32_t* status);
 
 /* ---------------------------------------------------------------------------------------
  * Optional loss terms (weights 0.0 / non-variational in vita.yaml:18-19,40-41).

@@ -109,3 +109,36 @@ def test_generate_actions_uses_it_and_matches():
     b = ops.generate_actions(ow, ob, fw, dw, obs, 6)
     torch.cuda.synchronize()
     assert torch.equal(a, b)
+
+
+def test_k100_robomimic_square_b4096_against_fp64_oracle():
+    """BASELINE configs[3] at its headline shape through the persistent launch: robomimic_square dims, 4096 rows, K = 100 (600
+    phases, team counters to 9 600) against the fp64 oracle on 16 sampled rows, and the status word."""
+    sd = O.make_state_dict(555, 7, seed=0)
+    fw = ops.FlowNetHandle(sd, DEV)
+    x0 = torch.randn(4096, 512, generator=torch.Generator().manual_seed(100)).to(DEV)
+    a = ops.ode_sample(fw, x0, 100)
+    assert ops.ode_sample_status(fw, 4096, 100, DEV) == 0
+    assert torch.isfinite(a).all()
+    idx = torch.arange(0, 4096, 256) + torch.arange(16) * 13
+    ref = O.euler_sample({k: v.double() for k, v in sd.items()}, x0[idx].cpu().double(), 100)
+    err = ((a[idx].cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-5, err
+
+
+def test_wide_net_h2048_b4096_against_fp64_oracle_and_position_independence():
+    """BASELINE configs[4] at its headline shape: hidden_dim 2048 (FF = 8192), 4096 rows, K = 6 (the per-launch path with the
+    folded LayerNorms: teams of 64 would not fit the persistent launch) against the fp64 oracle on sampled rows; and a row's
+    result does not depend on where in the batch it sits, bit for bit."""
+    sd = O.make_state_dict(533, 21, hidden_dim=2048, seed=3)
+    fw = ops.FlowNetHandle(sd, DEV)
+    x0 = torch.randn(4096, 512, generator=torch.Generator().manual_seed(2048)).to(DEV)
+    a = ops.ode_sample(fw, x0, 6)
+    assert torch.isfinite(a).all()
+    idx = torch.tensor([0, 63, 64, 255, 256, 1000, 2047, 2048, 3333, 4095])
+    ref = O.euler_sample({k: v.double() for k, v in sd.items()}, x0[idx].cpu().double(), 6)
+    err = ((a[idx].cpu().double() - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 1e-5, err
+    perm = torch.randperm(4096, generator=torch.Generator().manual_seed(5)).to(DEV)
+    b = ops.ode_sample(fw, x0[perm].contiguous(), 6)
+    assert torch.equal(b, a[perm])

@@ -167,6 +167,9 @@ SIGNATURES = {
     "vita_debug_ode_stamps": (C.c_int, [c_fp]),
     "vita_ode_sample_status": (C.c_int, [C.POINTER(FlowNetWeights), C.c_int32, C.c_int32, c_fp, C.POINTER(C.c_int32)]),
     "vita_generate_actions_status": (C.c_int, [C.POINTER(FlowNetWeights), C.c_int32, C.c_int32, c_fp, C.POINTER(C.c_int32)]),
+    "vita_generate_actions_noalloc_status": (C.c_int, [C.POINTER(FlowNetWeights), C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
+    "vita_generate_actions_bf16_status": (C.c_int, [C.POINTER(FlowNetWeights), C.c_int32, C.c_int32, C.c_int32, c_fp, C.POINTER(C.c_int32)]),
+    "vita_debug_set_spin_limit": (C.c_int, [C.c_uint32]),
     "vita_decoder_forward_workspace_bytes": (C.c_size_t, [C.POINTER(DecoderWeights), C.c_int32]),
     "vita_decoder_forward_f32": (C.c_int, [C.POINTER(DecoderWeights), c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32,
                                            c_fp, C.c_size_t, c_fp]),

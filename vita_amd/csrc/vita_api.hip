@@ -424,6 +424,8 @@ int vita_generate_actions_status(const vita_flownet_weights* fw, int32_t B, int3
     return vita_ode_sample_status(fw, B, num_steps, rest, status);
 }
 
+int vita_debug_set_spin_limit(uint32_t spins) { set_ode_spin_limit(spins); return VITA_OK; }
+
 size_t vita_consistency_sample_workspace_bytes(const vita_flownet_weights* w, int32_t B, int32_t num_steps) {
     if (!w || B <= 0 || num_steps <= 0) return 0;
     return carve_flow(nullptr, w, B, num_steps, true, false).bytes;
@@ -547,6 +549,17 @@ int vita_generate_actions_noalloc_f32(const float* obs_w, const float* obs_b, in
     struct SymbolScope { SymbolScope() { tl_ws_symbol = true; } ~SymbolScope() { tl_ws_symbol = false; } } sym;
     return generate_actions_run(obs_w, obs_b, O, fw, dw, obs_features, ldobs, actions, lda, latents_out, B, num_steps, ws,
                                 (hipStream_t)stream);
+}
+
+
+// status word of the last vita_generate_actions_noalloc_f32 call with these shapes on the current device (synchronises that copy)
+int vita_generate_actions_noalloc_status(const vita_flownet_weights* fw, int32_t B, int32_t num_steps, int32_t* status) {
+    const char* who = "vita_generate_actions_noalloc_status";
+    VITA_REQUIRE(fw && status && B > 0 && num_steps > 0, "%s: bad arguments", who);
+    void* ws = nullptr;
+    VITA_TRY(noalloc_scratch(&ws, who));
+    SkbScope skb((size_t)VITA_NOALLOC_SPLITK_BYTES);      // the carve of the call it reports on
+    return vita_generate_actions_status(fw, B, num_steps, ws, status);
 }
 
 }  // extern "C"

@@ -245,4 +245,22 @@ int vita_generate_actions_bf16(const float* obs_b, int32_t O, const vita_flownet
     return decoder_b(dw, bw, latb, actions, lda, B, rest, s);
 }
 
+
+int vita_generate_actions_bf16_status(const vita_flownet_weights* fw, int32_t O, int32_t B, int32_t num_steps, const void* workspace,
+                                      int32_t* status) {
+    VITA_REQUIRE(fw && workspace && status && B > 0 && num_steps > 0 && O > 0, "vita_generate_actions_bf16_status: bad arguments");
+    *status = 0;
+    Carver c(const_cast<void*>(workspace));      // the carve of vita_generate_actions_bf16
+    c.take(kSplitkBytes / sizeof(float));
+    c.take((size_t)B * fw->D);
+    take16(c, (size_t)B * r8(fw->D));
+    take16(c, (size_t)B * r8(O));
+    FlowWsB f = carve_flow_b(static_cast<char*>(const_cast<void*>(workspace)) + c.off, fw, B, num_steps);
+    if (f.sync == nullptr) return VITA_OK;
+    unsigned v = 0;
+    VITA_CHECK_HIP(hipMemcpy(&v, reinterpret_cast<const char*>(f.sync) + ode_persistent_status_offset(), sizeof(v), hipMemcpyDeviceToHost));
+    *status = (int32_t)v;
+    return VITA_OK;
+}
+
 }  // extern "C"

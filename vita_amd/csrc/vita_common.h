@@ -37,12 +37,13 @@ void set_error(const char* fmt, ...);
 // 0.5*(1+tanh(u)) == 1/(1+exp(-2u)); avoids the cancellation of the tanh form and costs one
 // v_exp_f32 + one division.  PyTorch: GeluKernel "tanh" approximation constants.
 __device__ __forceinline__ float act_gelu_tanh(float x) {
-    const float kBeta = 0.7978845608028654f;  // sqrt(2/pi)
-    const float kKappa = 0.044715f;
-    const float x3 = x * x * x;
-    const float inner = kBeta * (x + kKappa * x3);
-    // exp(-2*inner) = exp2(-2*log2(e)*inner): v_exp_f32 and v_rcp_f32 are 1-ulp instructions
-    const float e = __builtin_amdgcn_exp2f(inner * -2.8853900817779268f);
+    // inner = sqrt(2/pi) * (x + 0.044715 x^3) = x * (beta + beta*kappa * x^2); exp(-2*inner) = exp2(x * (c0 + c1 * x^2)) with the
+    // -2*log2(e) factor folded into the two constants: mul, fma, mul, v_exp_f32, add, v_rcp_f32, mul (v_exp_f32 and v_rcp_f32
+    // are 1-ulp instructions).  Round 3: 7 VALU operations instead of 10 -- fc1's epilogue is bound by them.
+    const float c0 = -2.8853900817779268f * 0.7978845608028654f;              // -2 log2(e) sqrt(2/pi)
+    const float c1 = -2.8853900817779268f * 0.7978845608028654f * 0.044715f;
+    const float p = fmaf(x * x, c1, c0);
+    const float e = __builtin_amdgcn_exp2f(x * p);
     return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 __device__ __forceinline__ float act_gelu_erf(float x) {

@@ -233,7 +233,7 @@ __device__ __forceinline__ void epilogue_tile(const f32x16 (&acc)[MI][NI], float
                                     // of the tile's rows, combined by the kernel's prologue (fold_row_stats)
                     const float mu = srow[lr * 2], rstd = srow[lr * 2 + 1];
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) a[k] = rstd * (a[k] - mu * c1[k]);
+                    for (int k = 0; k < 4; ++k) a[k] = rstd * fmaf(-mu, c1[k], a[k]);
                 }
                 f32x4 zin = {0.f, 0.f, 0.f, 0.f}, rs = zin, g = gv, pre, out;
                 if constexpr (BWD) {

@@ -28,6 +28,12 @@ int set_ode_persistent(int on);   // returns the previous setting
 void set_ode_persistent_stamps(void* device_buf);
 void* ode_persistent_stamps();
 size_t ode_persistent_status_offset();
+// In-launch samplers' failure path (round 3): behind the launch, words != 0 in the sticky status word turn `buf` (rows x cols 32-bit
+// words, row stride ld words) into NaN (0x7FC07FC0: a NaN as one fp32 and as two bf16), so a bounded hand-off wait that ran out
+// travels with the data instead of leaving undefined values; no host synchronisation.
+int launch_poison_on_timeout(const void* sync, void* buf, int64_t ld_words, int64_t rows, int64_t cols_words, hipStream_t s);
+unsigned ode_spin_limit();          // bound of every hand-off spin (vita_debug_set_spin_limit; default 1 << 22)
+void set_ode_spin_limit(unsigned n);
 int device_cus();                  // compute units of the current device (cached per device; <= 0: unknown)
 bool ode_persistent_enabled();     // the process-wide switch (VITA_NO_PERSISTENT / vita_ode_sample_set_persistent)
 // the weights-resident Euler sampler for serving batches (vita_ode_resident.hip): one launch, weights in LDS for all K steps

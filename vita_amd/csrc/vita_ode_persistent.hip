@@ -305,7 +305,7 @@ static int launch_persistent(OdeParams& q, int L, void* sync, hipStream_t s) {
     VITA_CHECK_HIP(hipGetLastError());
     PersistArgs a{};
     a.table = table; a.sync = static_cast<unsigned*>(sync); a.nphases = nphases; a.TS = TS;
-    a.spin_limit = 1u << 22;      // ~ seconds: only a lost workgroup gets there
+    a.spin_limit = ode_spin_limit();
     a.stamps = g_stamps.load();
     for (int rg0 = 0; rg0 < q.B / 256; rg0 += rg_per_launch) {
         a.rg0 = rg0;
@@ -315,6 +315,10 @@ static int launch_persistent(OdeParams& q, int L, void* sync, hipStream_t s) {
         else hipLaunchKernelGGL(ode_persistent_kernel<false>, dim3((unsigned)(rg_per_launch * TS)), dim3(DNT), lds, s, a);
         VITA_CHECK_HIP(hipGetLastError());
     }
+    // a timed-out launch leaves NaN, not undefined values, in everything the caller reads (vita_ode_resident.hip)
+    VITA_TRY(launch_poison_on_timeout(sync, q.x_out, q.ldo, q.B, q.w.D, s));
+    if (q.traj) VITA_TRY(launch_poison_on_timeout(sync, q.traj, q.w.D, (int64_t)(q.K + 1) * q.B, q.w.D, s));
+    if (q.bf16 && q.xb_final) VITA_TRY(launch_poison_on_timeout(sync, q.xb_final, ((q.w.D + 7) / 8 * 8) / 2, q.B, ((q.w.D + 7) / 8 * 8) / 2, s));
     return VITA_OK;
 }
 

@@ -707,6 +707,27 @@ __global__ __launch_bounds__(RS_NT) void ode_resident_kernel(ResidentArgs q) {
     }
 }
 
+// ---- the failure path of both in-launch samplers ---------------------------------------------------------------------
+// A workgroup whose bounded wait ran out has left with its outputs unwritten (vita_ode_persistent.hip TeamSync, GridSync above):
+// this kernel, enqueued behind the launch, reads the call's sticky status word and overwrites the outputs with NaN when it is
+// set, so nobody can consume undefined actions without noticing (the word itself needs a host read: vita_*_status).
+__global__ void poison_on_timeout_kernel(const unsigned* sync, unsigned* buf, int64_t ld, int64_t rows, int64_t cols) {
+    if (sync[kStickyWord] == 0) return;      // across a kernel boundary: a plain load reads the launch's stores
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x)
+        for (int64_t c = threadIdx.x; c < cols; c += blockDim.x) buf[r * ld + c] = 0x7FC07FC0u;
+}
+int launch_poison_on_timeout(const void* sync, void* buf, int64_t ld_words, int64_t rows, int64_t cols_words, hipStream_t s) {
+    if (buf == nullptr || rows <= 0 || cols_words <= 0) return VITA_OK;
+    const unsigned grid = (unsigned)(rows < 512 ? rows : 512);
+    hipLaunchKernelGGL(poison_on_timeout_kernel, dim3(grid), dim3(256), 0, s, static_cast<const unsigned*>(sync), static_cast<unsigned*>(buf),
+                       ld_words, rows, cols_words);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+static std::atomic<unsigned> g_spin_limit{1u << 22};      // ~ seconds: only a lost workgroup gets there
+unsigned ode_spin_limit() { return g_spin_limit.load(std::memory_order_relaxed); }
+void set_ode_spin_limit(unsigned n) { g_spin_limit.store(n == 0 ? (1u << 22) : n, std::memory_order_relaxed); }
+
 // ---- host side -------------------------------------------------------------------------------------------------------
 static std::atomic<int> g_cus[64];
 int device_cus() {
@@ -765,7 +786,7 @@ int launch_ode_resident(const vita_flownet_weights* w, const float* x0, int64_t 
     a.tp = thid != nullptr ? 1 : 0; a.thid = thid; a.tsilu = tsilu;
     a.sync = static_cast<unsigned*>(sync);
     a.B = B; a.K = K; a.dt = dt;
-    a.spin_limit = 1u << 22;
+    a.spin_limit = ode_spin_limit();
     a.acquire = (acquire || force_acquire) ? 1 : 0;
     a.stamps = static_cast<unsigned long long*>(ode_persistent_stamps());
     if (obs != nullptr) { a.obs_w = obs->w; a.obs_b = obs->b; a.obs = obs->x; a.ldobs = obs->ldx; a.O = obs->O; }
@@ -775,6 +796,10 @@ int launch_ode_resident(const vita_flownet_weights* w, const float* x0, int64_t 
     VITA_CHECK_HIP(hipMemsetAsync(sync, 0, ode_sync_words_bytes(), s));      // counters, timeout word, status word
     hipLaunchKernelGGL(ode_resident_kernel, dim3(RS_WG), dim3(RS_NT), rs_smem_floats(w->L) * sizeof(float), s, a);
     VITA_CHECK_HIP(hipGetLastError());
+    // a timed-out launch leaves NaN, not undefined values, in everything the caller reads
+    VITA_TRY(launch_poison_on_timeout(sync, x_out, ldo, B, w->D, s));
+    if (traj) VITA_TRY(launch_poison_on_timeout(sync, traj, w->D, (int64_t)(K + 1) * B, w->D, s));
+    if (dw != nullptr) VITA_TRY(launch_poison_on_timeout(sync, actions, lda, B, dw->OUT, s));
     return VITA_OK;
 }
 

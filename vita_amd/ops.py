@@ -259,6 +259,33 @@ def generate_actions_status(fw: FlowNetHandle, dw: "DecoderHandle", B: int, num_
     return int(st.value)
 
 
+def generate_actions_noalloc_status(fw: FlowNetHandle, B: int, num_steps: int, device) -> int:
+    """vita_generate_actions_noalloc_status: the status word of the last generate_actions_noalloc with these shapes on
+    `device` (synchronises)."""
+    lib = L.load()
+    torch.cuda.synchronize(device)
+    st = C.c_int32(0)
+    with torch.cuda.device(device):
+        L.check(lib.vita_generate_actions_noalloc_status(C.byref(fw.w), B, num_steps, C.byref(st)), "vita_generate_actions_noalloc_status")
+    return int(st.value)
+
+
+def generate_actions_bf16_status(fw: FlowNetHandle, dw: "DecoderHandle", O: int, B: int, num_steps: int, device) -> int:
+    """vita_generate_actions_bf16_status for the cached workspace the last generate_actions_bf16 on `device` used (synchronises)."""
+    lib = L.load()
+    torch.cuda.synchronize(device)
+    nbytes = lib.vita_generate_actions_bf16_workspace_bytes(C.byref(fw.w), C.byref(dw.w), O, B, num_steps)
+    ws = workspace(torch.device(device), nbytes)
+    st = C.c_int32(0)
+    L.check(lib.vita_generate_actions_bf16_status(C.byref(fw.w), O, B, num_steps, ws.data_ptr(), C.byref(st)), "vita_generate_actions_bf16_status")
+    return int(st.value)
+
+
+def set_sampler_spin_limit(spins: int) -> None:
+    """Diagnostic: the bound of the in-launch samplers' hand-off spins (0 = the default); a tiny bound forces the time-out path."""
+    L.check(L.load().vita_debug_set_spin_limit(int(spins)), "vita_debug_set_spin_limit")
+
+
 def set_persistent_sampler(on: bool) -> bool:
     """Process-wide switch of vita_ode_sample_f32 / vita_generate_actions_f32 between the persistent launch and the
     per-launch path; returns the previous setting."""

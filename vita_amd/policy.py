@@ -336,6 +336,8 @@ class VitaPolicy(nn.Module):
         self.normalize_targets = Normalize([task.action_key], stats)
         self.unnormalize_outputs = Unnormalize([task.action_key], stats)
         self._action_queue = None
+        self._last_solve = None
+        self.check_status = True       # select_action raises when the in-launch sampler timed out (check_sampler_status)
         # vita_policy.py:41-74
         self.num_sampling_steps = pol.flow_matcher.num_sampling_steps
         if isinstance(observer, str):
@@ -851,7 +853,27 @@ class VitaPolicy(nn.Module):
         else:
             out = ops.generate_actions(self.obs_encoder.weight.data, self.obs_encoder.bias.data, fw, dw, obs_features,
                                        self.num_sampling_steps)
+        self._last_solve = (obs_features.shape[0], obs_features.shape[1], obs_features.device)
         return out.view(-1, self.pred_horizon, self.action_dim)
+
+    def check_sampler_status(self):
+        """Raises VitaHipError when the last generate_actions' in-launch sampler timed out (a bounded hand-off wait ran out:
+        csrc/vita_ode_persistent.hip TeamSync, csrc/vita_ode_resident.hip GridSync).  Its outputs are NaN then (the library
+        poisons them on the device); this is the host-side half.  SYNCHRONISES: select_action and validate call it where they
+        wait for the device anyway."""
+        last = getattr(self, "_last_solve", None)
+        if last is None:
+            return
+        B, O, device = last
+        fw, dw, _ = self._infer_handles()
+        if self.gemm_dtype != "f32":
+            st = ops.generate_actions_bf16_status(fw, dw, O, B, self.num_sampling_steps, device)
+        else:
+            st = ops.generate_actions_status(fw, dw, B, self.num_sampling_steps, device)
+        if st != 0:
+            raise L.VitaHipError(f"the in-launch Euler sampler timed out in phase {st - 1} (B={B}, K={self.num_sampling_steps}): another kernel "
+                                 "held compute units its workgroups needed; the actions of that call are NaN.  Re-run, or select the "
+                                 "per-launch path with vita_amd.ops.set_persistent_sampler(False)")
 
     def _bf16_weights(self):
         """bf16 copies of the GEMM weights, re-packed whenever a parameter has been written since the last pack."""
@@ -873,6 +895,8 @@ class VitaPolicy(nn.Module):
         batch = self.normalize_inputs(batch)
         if len(self._action_queue) == 0:
             actions = self.generate_actions(batch)
+            if self.check_status:       # the caller copies the action to the host next (utils/eval.py:99): this wait is that wait
+                self.check_sampler_status()
             actions = actions[:, :self.action_horizon]
             actions = self.unnormalize_outputs({"action": actions})["action"]
             self._action_queue.extend(actions.transpose(0, 1))
@@ -889,6 +913,7 @@ class VitaPolicy(nn.Module):
         pred_norm = self.generate_actions(batch)
         torch.cuda.synchronize()
         gen_time_ms = (time.perf_counter() - t0) * 1000 / batch_size
+        self.check_sampler_status()
         pred = self.unnormalize_outputs({"action": pred_norm})["action"]
         gt = batch[ak]
         with torch.no_grad():
