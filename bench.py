@@ -215,6 +215,41 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
     chunks_per_s = world * B * args.steps / elapsed
 
+    # ---- strong scaling (BASELINE configs[3]): ONE global batch of `B` rows cut into contiguous row shards
+    # (vita_amd.parallel.shard_range), no collective on the data path.  N > 1: every rank runs its shard, max over ranks.
+    # N == 1: the shard sizes of N = 2 / 4 / 8 timed on this GPU -- what each rank of such a job runs (rows are independent, so
+    # this is the job's time up to box-to-box clock differences).
+    from vita_amd.parallel import shard_range
+
+    def time_rows(rows, iters):
+        o_, y_ = obs[:rows].contiguous(), torch.empty(rows, dw.OUT, device=dev)
+        for _ in range(3):
+            ops.generate_actions(ow, ob, fw, dw, o_, K, out=y_)
+        fence()
+        t0_ = time.perf_counter()
+        for _ in range(iters):
+            ops.generate_actions(ow, ob, fw, dw, o_, K, out=y_)
+        fence()
+        return (time.perf_counter() - t0_) / iters
+
+    strong = None
+    if world > 1:
+        lo, hi = shard_range(B, rank, world)
+        ts_ = torch.tensor([time_rows(hi - lo, args.steps)], device=dev, dtype=torch.float64)
+        dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+        strong = {"global_batch": B, "rows_per_gpu": hi - lo, "ms_per_step": round(ts_.item() * 1e3, 4),
+                  "chunks_per_s": round(B / ts_.item(), 1),
+                  "efficiency_vs_one_gpu_same_run": round((ms_per_step * 1e-3) / (world * ts_.item()), 4),
+                  "note": "one 4096-row batch sharded by rows over the ranks, no collective; efficiency = (time of all 4096 rows on one GPU, "
+                          "this run's weak leg) / (N x time of the shard)"}
+    else:
+        strong = {"global_batch": B, "predicted_from_one_gpu": True, "shards": {}}
+        for n_ in (2, 4, 8):
+            rows = shard_range(B, 0, n_)[1]
+            t_ = time_rows(rows, max(5, args.steps))
+            strong["shards"][f"{n_}_gpus"] = {"rows_per_gpu": rows, "ms_per_step": round(t_ * 1e3, 4), "chunks_per_s": round(B / t_, 1),
+                                              "efficiency_vs_one_gpu": round((ms_per_step * 1e-3) / (n_ * t_), 4)}
+
     # latent-only sampler (B,D)->(B,D): "the fused ODE sampler" of the north star.  At chip-filling batches it is ONE persistent
     # launch per solve (+ a few tiny time-path launches): HIP events on the launch stream around n solves
     x0 = torch.randn(B, fw.D, generator=g).to(dev)
@@ -516,6 +551,7 @@ def main():
             "train_large_batch_bf16": train_large_bf16,
             "bf16_variant": bf16,
             "serving_latency": serving,
+            "strong_scaling": strong,
             "cpu_baseline": cpu,
         }
         print(json.dumps(line), flush=True)

@@ -341,17 +341,22 @@ int vita_adamw_ema_step_f32(float* p, const float* g, float* m, float* v, float*
  *     is_pad[b, j] = (i + delta[j] < lo) | (i + delta[j] >= hi)      :314-319   (is_pad may be NULL)
  * delta: the key's delta indices, round(delta_timestamp * fps) (lerobot get_delta_indices).  Every pointer is device memory;
  * indices are int64 as torch.LongTensor holds them.
+ * Bounds (round 3): num_frames = N, num_episodes = E.  As numpy / zarr indexing does, idx[b] < 0 wraps once (idx + N); an index
+ * still outside [0, N), or an episode id outside [0, E), never leaves the buffer: the row is read from frame 0, flagged as
+ * padding, and *err (NULL, or one device word the caller zeroed) is set to 1 -- the reference raises IndexError there, and so
+ * does vita_amd.data.DeviceReplayDataset.batch (before the launch for host-side index lists, from err for device tensors
+ * when asked to check).
  * vita_gather_window_f32: src (N, R) float rows with row stride ld_src (states, actions, precomputed camera latents) ->
  *     out (B, T, R).
  * vita_gather_window_u8_nchw_f32: src (N, H, W, C) uint8 images -> out (B, T, C, H, W) float32 = value / 255, the
  *     `.type(torch.float32).permute(0, 3, 1, 2) / 255.0` of :355-356 (C in {1, 3, 4}; B * T <= 65535 per call).
  * --------------------------------------------------------------------------------------- */
 int vita_gather_window_f32(const float* src, int64_t ld_src, int32_t R, const int64_t* idx, int32_t B, const int64_t* delta, int32_t T,
-                           const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, float* out, uint8_t* is_pad,
-                           vita_stream_t stream);
+                           const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, int64_t num_frames, int64_t num_episodes,
+                           float* out, uint8_t* is_pad, int32_t* err, vita_stream_t stream);
 int vita_gather_window_u8_nchw_f32(const uint8_t* src, int32_t H, int32_t W, int32_t C, const int64_t* idx, int32_t B, const int64_t* delta,
-                                   int32_t T, const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, float* out, uint8_t* is_pad,
-                                   vita_stream_t stream);
+                                   int32_t T, const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, int64_t num_frames,
+                                   int64_t num_episodes, float* out, uint8_t* is_pad, int32_t* err, vita_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * The observer's elementwise tail.  ResNetObserver's backbone (flare/policies/observers/resnet_observer.py:40-44:

@@ -24,8 +24,9 @@ def query_indices(idx, lo, hi, delta):
     return q, pad
 
 
-def get_item(arrays, ep_from, ep_to, delta_indices, image_keys, idx):
-    """av_aloha_dataset.py:349-361 (no image_transforms, no task string)."""
+def get_item(arrays, ep_from, ep_to, delta_indices, image_keys, idx, image_transforms=None, tasks=None):
+    """av_aloha_dataset.py:349-372; image_transforms: a callable on one item's (T, C, H, W) float array (:362-365); tasks: the
+    {task_index: str} table, used when delta_indices holds 'task_index' (:264-266, 367-370)."""
     ep = int(arrays["episode_index"][idx])
     lo, hi = int(ep_from[ep]), int(ep_to[ep])
     item = {"episode_index": np.int64(ep)}
@@ -35,14 +36,18 @@ def get_item(arrays, ep_from, ep_to, delta_indices, image_keys, idx):
         val = arrays[key][q]
         if key in image_keys:
             val = val.astype(np.float32).transpose(0, 3, 1, 2) / np.float32(255.0)
+        if key in image_keys and image_transforms is not None:
+            val = image_transforms(val)
         item[key] = val
+    if "task_index" in item and tasks is not None:
+        item["task"] = tasks[int(item["task_index"].item())]
     return item
 
 
 def collate(items):
     """torch.utils.data.default_collate on dicts of arrays: stack along a new first axis."""
-    return {k: np.stack([it[k] for it in items]) for k in items[0]}
+    return {k: ([it[k] for it in items] if isinstance(items[0][k], str) else np.stack([it[k] for it in items])) for k in items[0]}
 
 
-def batch(arrays, ep_from, ep_to, delta_indices, image_keys, indices):
-    return collate([get_item(arrays, ep_from, ep_to, delta_indices, image_keys, int(i)) for i in indices])
+def batch(arrays, ep_from, ep_to, delta_indices, image_keys, indices, image_transforms=None, tasks=None):
+    return collate([get_item(arrays, ep_from, ep_to, delta_indices, image_keys, int(i), image_transforms, tasks) for i in indices])

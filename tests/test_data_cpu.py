@@ -64,3 +64,21 @@ def test_index_helpers():
     assert get_delta_indices({"a": [i / 25 for i in range(-1, 16)]}, 25) == {"a": list(range(-1, 16))}
     edi = get_episode_data_index([3, 1, 4])
     assert edi["from"].tolist() == [0, 3, 4] and edi["to"].tolist() == [3, 4, 8]
+
+
+def test_oracle_item_extras_match_the_reference(gold):
+    """av_aloha_dataset.py:264-266, 362-370: 'task_index' joins the window keys, image_transforms runs on every camera key of an
+    item, the task's string joins the item; default_collate keeps the strings as a list."""
+    g, meta = gold
+    arrays = {k[len("buffer/"):]: v.numpy() for k, v in g.items() if k.startswith("buffer/")}
+    arrays["task_index"] = g["extras/task_index"].numpy()
+    edi = get_episode_data_index(meta["lengths"])
+    tasks = {int(k): v for k, v in meta["extras/tasks"].items()}
+    b = DO.batch(arrays, edi["from"].numpy(), edi["to"].numpy(), dict(meta["delta_indices"], task_index=[0]), meta["image_keys"],
+                 g["batch/indices"].tolist(), image_transforms=lambda x: x[..., ::-1] * np.float32(0.5) + np.float32(0.25), tasks=tasks)
+    assert b.pop("task") == meta["extras/task"]
+    want = {k[len("extras/out/"):]: v.numpy() for k, v in g.items() if k.startswith("extras/out/")}
+    assert set(b) == set(want)
+    for k, v in want.items():
+        got = b[k].astype(np.uint8) if b[k].dtype == bool else b[k]
+        assert got.shape == v.shape and np.array_equal(got, v), k

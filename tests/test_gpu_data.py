@@ -43,6 +43,41 @@ def test_device_batches_are_the_reference_items_bit_for_bit(golden_dir):
     assert batch["observation.images.cam"].dtype == torch.float32 and batch["action_is_pad"].dtype == torch.bool
 
 
+def test_item_extras_and_index_bounds(golden_dir):
+    """image_transforms, 'task_index' and the 'task' strings of AVAlohaDataset.__getitem__ (av_aloha_dataset.py:264-266, 362-370)
+    against the reference's own items; and the index bounds of numpy / zarr indexing: -1 is the last frame, N raises."""
+    g = {}
+    with safe_open(os.path.join(golden_dir, "dataset.safetensors"), framework="pt") as f:
+        for k in f.keys():
+            g[k] = f.get_tensor(k)
+    meta = json.load(open(os.path.join(golden_dir, "dataset.json")))
+    arrays = {k[len("buffer/"):]: v.numpy() for k, v in g.items() if k.startswith("buffer/")}
+    arrays["task_index"] = g["extras/task_index"].numpy()
+    fps = 10
+    tasks = {int(k): v for k, v in meta["extras/tasks"].items()}
+    ds = DeviceReplayDataset(arrays, meta["lengths"], {k: [d / fps for d in v] for k, v in meta["delta_indices"].items()}, fps,
+                             image_keys=meta["image_keys"], device=DEV, image_transforms=lambda x: x.flip(-1) * 0.5 + 0.25, tasks=tasks)
+    batch = ds.batch(g["batch/indices"])
+    assert batch.pop("task") == meta["extras/task"]
+    _check(batch, {k[len("extras/out/"):]: v.numpy() for k, v in g.items() if k.startswith("extras/out/")})
+    N = len(ds)
+    last, wrapped = ds.batch([N - 1]), ds.batch([-1])
+    for k in last:
+        assert last[k] == wrapped[k] if k == "task" else torch.equal(last[k], wrapped[k]), k
+    with pytest.raises(IndexError):
+        ds.batch([0, N])
+    with pytest.raises(IndexError):
+        ds.batch([-N - 1])
+    # device-side index tensors: the kernels keep the reads inside the buffer and report through the error word
+    ok = ds.batch(torch.tensor([-1, 3], device=DEV), check_indices=True)
+    assert torch.equal(ok["action"][0], last["action"][0])
+    with pytest.raises(IndexError):
+        ds.batch(torch.tensor([1, N + 5], device=DEV), check_indices=True)
+    unchecked = ds.batch(torch.tensor([1, N + 5], device=DEV))        # no fault, the row is flagged as padding
+    assert bool(unchecked["action_is_pad"][1].all()) and not bool(unchecked["action_is_pad"][0].any())
+    ds._err.zero_()
+
+
 def test_large_ragged_buffer_against_the_oracle():
     rng = np.random.default_rng(3)
     lengths = rng.integers(1, 60, size=70).tolist() + [1, 2, 300]

@@ -101,6 +101,23 @@ def main():
         out[f"batch/out/{k}"] = (v.to(torch.uint8) if v.dtype == torch.bool else v).contiguous()
     for k, v in arrays.items():
         out[f"buffer/{k}"] = torch.from_numpy(v)
+    # ---- the item extras (av_aloha_dataset.py:264-266, 362-370): a 'task_index' feature adds delta_timestamps['task_index'] = [0]
+    # (what __init__ does), image_transforms runs on every camera key, and the task's string joins the item
+    arrays2 = dict(arrays, task_index=rng.integers(0, 3, size=N).astype(np.int64))
+    ds2 = object.__new__(avd.AVAlohaDataset)
+    ds2.episode_data_index = edi
+    ds2.delta_indices = dict(delta_indices, task_index=[0])
+    ds2.replay_buffer = arrays2
+    ds2.image_transforms = lambda x: x.flip(-1) * 0.5 + 0.25       # any callable on the (T, C, H, W) float frames of one item
+    tasks = {0: "hook the package", 1: "thread the needle", 2: "push the T"}
+    ds2.meta = types.SimpleNamespace(image_keys=["observation.images.cam"], video_keys=[], camera_keys=["observation.images.cam"], tasks=tasks,
+                                     features={"task_index": {}}, stats={}, fps=10)
+    batch2 = torch.utils.data.default_collate([ds2[i] for i in indices])
+    meta["extras/tasks"] = {str(k): v for k, v in tasks.items()}
+    meta["extras/task"] = list(batch2.pop("task"))                  # default_collate keeps the strings as a list
+    for k, v in batch2.items():
+        out[f"extras/out/{k}"] = (v.to(torch.uint8) if v.dtype == torch.bool else v).contiguous()
+    out["extras/task_index"] = torch.from_numpy(arrays2["task_index"])
     meta["lengths"], meta["delta_indices"], meta["image_keys"] = lengths, delta_indices, ["observation.images.cam"]
     save_file(out, os.path.join(REPO, "tests", "golden", "dataset.safetensors"))
     json.dump(meta, open(os.path.join(REPO, "tests", "golden", "dataset.json"), "w"), indent=1)

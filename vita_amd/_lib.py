@@ -206,9 +206,10 @@ SIGNATURES = {
     "vita_action_encoder_workspace_bytes": (C.c_size_t, [C.POINTER(EncoderWeights), C.c_int32]),
     "vita_action_encoder_forward_f32": (C.c_int, [C.POINTER(EncoderWeights), c_fp, c_fp, C.c_int64, C.c_int32, c_fp, C.c_size_t,
                                                   c_fp]),
-    "vita_gather_window_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp, c_fp, c_fp, c_fp]),
+    "vita_gather_window_f32": (C.c_int, [c_fp, C.c_int64, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp, C.c_int64, C.c_int64,
+                                         c_fp, c_fp, c_fp, c_fp]),
     "vita_gather_window_u8_nchw_f32": (C.c_int, [c_fp, C.c_int32, C.c_int32, C.c_int32, c_fp, C.c_int32, c_fp, C.c_int32, c_fp, c_fp, c_fp,
-                                                 c_fp, c_fp, c_fp]),
+                                                 C.c_int64, C.c_int64, c_fp, c_fp, c_fp, c_fp]),
     "vita_channel_affine_relu_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_channel_affine_relu_bwd_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),
     "vita_affine_relu_maxpool3s2_f32": (C.c_int, [c_fp, c_fp, c_fp, c_fp, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp]),

@@ -17,15 +17,26 @@ struct WindowArgs {
     const int64_t* ep_from;              // (E) first frame of every episode
     const int64_t* ep_to;                // (E) one past the last frame
     unsigned char* is_pad;               // NULL or (B, T): 1 where idx + delta fell outside the episode (av_aloha_dataset.py:314-319)
+    int64_t N; int64_t E;                // frames / episodes of the replay buffer: bounds of idx and of ep_index's values
+    int* err;                            // NULL or one word: set to 1 when an index (after wrapping) or an episode id is out of range
 };
 
 // source frame of (b, j), _get_query_indices (:307-313): max(ep_start, min(ep_end - 1, idx + delta))
 __device__ __forceinline__ int64_t window_source(const WindowArgs& a, int b, int j, bool* pad) {
-    const int64_t i = a.idx[b];
-    const int64_t ep = a.ep_index[i];
-    const int64_t lo = a.ep_from[ep], hi = a.ep_to[ep];
+    // the reference indexes numpy / zarr arrays: a negative index wraps once, anything else outside [0, N) raises IndexError.
+    // Here an out-of-range index never leaves the buffer: it reads frame 0, flags the row as padding and sets *err (the host
+    // wrapper raises IndexError for host-side index lists before the launch; device-side index tensors are checked through err)
+    int64_t i = a.idx[b];
+    if (i < 0) i += a.N;
+    bool bad = i < 0 || i >= a.N;
+    if (bad) i = 0;
+    int64_t ep = a.ep_index[i];
+    if (ep < 0 || ep >= a.E) { bad = true; ep = 0; }
+    if (bad && a.err) *a.err = 1;
+    int64_t lo = a.ep_from[ep], hi = a.ep_to[ep];
+    if (lo < 0 || hi > a.N || lo >= hi) { lo = i; hi = i + 1; if (a.err) *a.err = 1; }
     const int64_t q = i + a.delta[j];
-    *pad = (q < lo) | (q >= hi);
+    *pad = (q < lo) | (q >= hi) | bad;
     return q < lo ? lo : (q > hi - 1 ? hi - 1 : q);
 }
 
@@ -99,20 +110,21 @@ using namespace vita;
 extern "C" {
 
 static int check_window(const char* who, const void* src, const int64_t* idx, int32_t B, const int64_t* delta, int32_t T, const int64_t* ep_index,
-                        const int64_t* ep_from, const int64_t* ep_to, const void* out) {
+                        const int64_t* ep_from, const int64_t* ep_to, const void* out, int64_t N, int64_t E) {
     VITA_REQUIRE(B >= 0 && T >= 1, "%s: bad batch / window (B=%d, T=%d)", who, B, T);
+    VITA_REQUIRE(B == 0 || (N >= 1 && E >= 1), "%s: the replay buffer needs at least one frame and one episode (N=%lld, E=%lld)", who, (long long)N, (long long)E);
     VITA_REQUIRE(B == 0 || (src && idx && delta && ep_index && ep_from && ep_to && out), "%s: null pointer", who);
     return VITA_OK;
 }
 
 int vita_gather_window_f32(const float* src, int64_t ld_src, int32_t R, const int64_t* idx, int32_t B, const int64_t* delta, int32_t T,
-                           const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, float* out, uint8_t* is_pad,
-                           vita_stream_t stream) {
+                           const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, int64_t num_frames, int64_t num_episodes,
+                           float* out, uint8_t* is_pad, int32_t* err, vita_stream_t stream) {
     const char* who = "vita_gather_window_f32";
-    VITA_TRY(check_window(who, src, idx, B, delta, T, ep_index, ep_from, ep_to, out));
+    VITA_TRY(check_window(who, src, idx, B, delta, T, ep_index, ep_from, ep_to, out, num_frames, num_episodes));
     VITA_REQUIRE(R >= 1 && ld_src >= R, "%s: bad row length / stride (R=%d, ld=%lld)", who, R, (long long)ld_src);
     if (B == 0) return VITA_OK;
-    WindowArgs a{idx, B, delta, T, ep_index, ep_from, ep_to, is_pad};
+    WindowArgs a{idx, B, delta, T, ep_index, ep_from, ep_to, is_pad, num_frames, num_episodes, err};
     const int vec = (R % 4 == 0) && (ld_src % 4 == 0) && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15u) == 0);
     hipLaunchKernelGGL(gather_window_f32_kernel, dim3((unsigned)B * (unsigned)T), dim3(256), 0, (hipStream_t)stream, src, ld_src, R, a, out, vec);
     VITA_CHECK_HIP(hipGetLastError());
@@ -120,14 +132,14 @@ int vita_gather_window_f32(const float* src, int64_t ld_src, int32_t R, const in
 }
 
 int vita_gather_window_u8_nchw_f32(const uint8_t* src, int32_t H, int32_t W, int32_t C, const int64_t* idx, int32_t B, const int64_t* delta,
-                                   int32_t T, const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, float* out, uint8_t* is_pad,
-                                   vita_stream_t stream) {
+                                   int32_t T, const int64_t* ep_index, const int64_t* ep_from, const int64_t* ep_to, int64_t num_frames,
+                                   int64_t num_episodes, float* out, uint8_t* is_pad, int32_t* err, vita_stream_t stream) {
     const char* who = "vita_gather_window_u8_nchw_f32";
-    VITA_TRY(check_window(who, src, idx, B, delta, T, ep_index, ep_from, ep_to, out));
+    VITA_TRY(check_window(who, src, idx, B, delta, T, ep_index, ep_from, ep_to, out, num_frames, num_episodes));
     VITA_REQUIRE(H >= 1 && W >= 1 && (C == 1 || C == 3 || C == 4) && (int64_t)H * W < (int64_t(1) << 30), "%s: bad image shape (%d, %d, %d)", who, H, W, C);
     VITA_REQUIRE((int64_t)B * T <= 65535, "%s: B * T = %lld images per launch exceed 65535", who, (long long)B * T);
     if (B == 0) return VITA_OK;
-    WindowArgs a{idx, B, delta, T, ep_index, ep_from, ep_to, is_pad};
+    WindowArgs a{idx, B, delta, T, ep_index, ep_from, ep_to, is_pad, num_frames, num_episodes, err};
     const int HW = H * W;
     if (HW % 4 == 0 && (reinterpret_cast<uintptr_t>(src) & 3u) == 0 && (reinterpret_cast<uintptr_t>(out) & 15u) == 0) {
         const dim3 grid4((unsigned)((HW / 4 + 255) / 256), (unsigned)B * (unsigned)T);

@@ -182,6 +182,9 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
     if (t128 >= 512) return launch_dma<128, 128, 32, 4>(p, stream);
     return launch_dma<64, 128, 64, 3>(p, stream);
 #else   // 5: 256x128 tiles when they still give every CU a tile (6 DMA issues per 64 MFMAs per wave instead of 4 per 32)
+#ifdef VITA_LAB_KG      // lab: the k-group count of the 64-row tile for short reductions
+    if (a.K <= 512 && (long)((a.M + 255) / 256) * ((a.N + 127) / 128) < 256) return launch_dma<64, 128, 64, 3, 2, VITA_LAB_KG>(p, stream);
+#endif
     if (fold == nullptr && (sk == nullptr || sk->splits <= 1)) {
         // (calls with the folded-LayerNorm epilogue keep the rule below: the persistent sampler walks the same tiles and must give
         // the same bits, tests/test_gpu_persistent.py)

@@ -294,7 +294,8 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 static int check_shape(const char* who, int64_t rows, int32_t C, int32_t HW) {
     VITA_REQUIRE(rows >= 0 && C >= 1 && HW >= 1 && rows % C == 0, "%s: rows (%lld) must be a multiple of C (%d), HW (%d) >= 1", who,
                  (long long)rows, C, HW);
-    VITA_REQUIRE(rows * (int64_t)HW < (int64_t)1 << 32, "%s: %lld x %d elements: at most 2^32 - 1 per call", who, (long long)rows, HW);
+    // the kernels index in 32-bit unsigned and round the grid up to whole 1024-element blocks: leave that block's headroom
+    VITA_REQUIRE(rows * (int64_t)HW <= ((int64_t)1 << 32) - 1024, "%s: %lld x %d elements: at most 2^32 - 1024 per call", who, (long long)rows, HW);
     return VITA_OK;
 }
 
