@@ -73,8 +73,8 @@ def test_item_extras_and_index_bounds(golden_dir):
     assert torch.equal(ok["action"][0], last["action"][0])
     with pytest.raises(IndexError):
         ds.batch(torch.tensor([1, N + 5], device=DEV), check_indices=True)
-    unchecked = ds.batch(torch.tensor([1, N + 5], device=DEV))        # no fault, the row is flagged as padding
-    assert bool(unchecked["action_is_pad"][1].all()) and not bool(unchecked["action_is_pad"][0].any())
+    unchecked = ds.batch(torch.tensor([5, N + 5], device=DEV))        # no fault, the row is flagged as padding
+    assert bool(unchecked["observation.state_is_pad"][1].all()) and not bool(unchecked["observation.state_is_pad"][0].any())
     ds._err.zero_()
 
 

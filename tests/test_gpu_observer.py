@@ -114,13 +114,63 @@ def test_train_step_through_the_backbone():
     assert nerr(leaf.grad, f64.grad) <= 2e-5
 
 
-def test_native_trainer_refuses_a_trainable_observer_loudly():
+def test_native_trainer_trains_the_observer():
+    """The native trainer (flat buffers, fused clip + AdamW + EMA, the data-parallel path) with a trainable backbone, as the reference
+    trains it in the same AdamW group (vita_policy.py:113-114, 222-229): loss_and_grads hands d loss / d features to torch's backward
+    of the observer alone and the backbone's gradients land in the observer's range of the flat gradient buffer.  Checked against
+    the drop-in path (compute_loss(...).backward()) on the same crop and the same t; then whole steps against the same step made of
+    torch's clip_grad_norm_ + AdamW on a twin policy."""
+    from vita_amd.trainer import PolicyTrainer
     cfg = _cfg()
+    cfg.scheduler_name = "constant"
+    cfg.optimizer_lr = 1e-3
+    cfg.optimizer_eps = 1e-3      # keeps the Adam direction well-conditioned where a gradient is ~0 (MIOpen's reductions are not bitwise)
+    cfg.use_ema = True
+    B = 12
+    batch = _batch(cfg, B)
+    t = torch.rand(B, generator=torch.Generator().manual_seed(1)).to(DEV)
+    twin = _policy(cfg)                                       # same seed: same weights
+    twin.train()
     pol = _policy(cfg)
+    tr = PolicyTrainer(cfg, pol, DEV, num_training_steps=100)
+    assert pol.observer_range is not None and pol.observer_range[1] == tr.flat.numel()
+    n_obs = sum(p.numel() for p in pol.observer.parameters() if p.requires_grad)
+    assert pol.observer_range[1] - pol.observer_range[0] == n_obs and tr.update_ranges[-1][1] == tr.flat.numel()
+    assert tr.plan[-1][:2] == pol.observer_range
+    # gradients of one call against the drop-in path
     pol.train()
-    nb = pol.normalize_targets(pol.normalize_inputs(_batch(cfg, 4)))
-    with pytest.raises(NotImplementedError, match="trainable observer"):
-        pol.loss_and_grads(nb)
+    nb = pol.normalize_targets(pol.normalize_inputs(batch))
+    torch.manual_seed(21)
+    pol.loss_and_grads(nb, t=t)
+    torch.manual_seed(21)
+    loss, _ = twin.compute_loss(twin.normalize_targets(twin.normalize_inputs(batch)), t=t)
+    loss.backward()
+    for (k, p), (_, q) in zip(pol.named_parameters(), twin.named_parameters()):
+        if q.grad is not None:
+            assert nerr(p.grad, q.grad) <= 1e-4, k            # MIOpen's weight-gradient reductions are not run-to-run bitwise
+    # two whole steps: normalise -> fused step + observer backward -> clip -> AdamW (+ EMA) on the flat buffers
+    opt = torch.optim.AdamW(twin.parameters(), lr=1e-3, betas=tuple(cfg.optimizer_betas), eps=cfg.optimizer_eps,
+                            weight_decay=cfg.optimizer_weight_decay)
+    w0 = pol.observer.backbone.conv1.weight.detach().clone()
+    for step in range(2):
+        torch.manual_seed(30 + step)
+        tr.train_step(batch, t=t)
+        opt.zero_grad()
+        torch.manual_seed(30 + step)
+        loss, _ = twin.compute_loss(twin.normalize_targets(twin.normalize_inputs(batch)), t=t)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(twin.parameters(), cfg.train.grad_clip_norm)
+        opt.step()
+    assert not torch.equal(w0, pol.observer.backbone.conv1.weight)
+    m = tr.metrics()
+    assert abs(m["loss"] - loss.item()) <= 1e-4 * abs(loss.item())
+    for (k, p), (_, q) in zip(pol.named_parameters(), twin.named_parameters()):
+        if q.requires_grad:
+            assert nerr(p, q) <= 2e-4, k
+    # the checkpoint covers the backbone's moments and EMA copies too
+    st = tr.training_state()
+    assert len(st["optimizer"]["state"]) == sum(1 for p in pol.parameters() if p.requires_grad)
+    assert len(st["ema"]["shadow_params"]) == len(list(pol.parameters()))
 
 
 def test_generate_and_select_action_from_frames():

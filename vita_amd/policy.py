@@ -471,6 +471,18 @@ class VitaPolicy(nn.Module):
             out += group
         return out
 
+    def observer_named_parameters(self):
+        """(name, parameter) of the observer's trainable tensors (the ResNet18 backbone's convolutions: the reference trains them
+        in the same AdamW group, vita_policy.py:222-229).  They follow the hot-path parameters in the flat buffers."""
+        obs = getattr(self, "observer", None)
+        if obs is None:
+            return []
+        return [(f"observer.{k}", p) for k, p in obs.named_parameters() if p.requires_grad]
+
+    def flat_named_parameters(self):
+        """Everything the native trainer's flat buffers hold, in buffer order: the hot path, then the observer."""
+        return self.hot_path_named_parameters() + self.observer_named_parameters()
+
     def _flow_event(self, key: str) -> int:
         """Gradient-ready event of a flow_net.* tensor of the default flow net (vita_loss_config.grad_ready_layers): 3 + l for
         layers.l.mlp.*, 3 + L for the outer projections and the final norm, 1 for the time path (time_embed, time_modulator);
@@ -505,6 +517,12 @@ class VitaPolicy(nn.Module):
                 else:
                     out.append((off, off + n))
             off += n
+        n_obs = sum(p.numel() for _, p in self.observer_named_parameters())
+        if n_obs:
+            if out and out[-1][1] == off:
+                out[-1] = (out[-1][0], off + n_obs)
+            else:
+                out.append((off, off + n_obs))
         return out
 
     def reduce_plan(self):
@@ -532,6 +550,10 @@ class VitaPolicy(nn.Module):
         last = max(ev for _, _, ev in plan)
         order = {0: -1, 2: last - 0.6, 1: last - 0.3} if last >= 3 else {}
         plan.sort(key=lambda seg: (order.get(seg[2], seg[2]), seg[0]))
+        n_obs = sum(p.numel() for _, p in self.observer_named_parameters())
+        if n_obs:       # the observer's gradients are final last: torch's backward of the backbone runs behind the fused step,
+                        # which hands it d loss / d features; its event (index last + 1) is recorded by loss_and_grads
+            plan.append((off, off + n_obs, last + 1))
         return plan
 
     def flatten_parameters(self):
@@ -541,7 +563,9 @@ class VitaPolicy(nn.Module):
         dev = named[0][1].device
         if dev.type != "cuda":
             raise L.VitaHipError("flatten_parameters: move the policy to the GPU first (policy.to('cuda:0'))")
-        n = sum(p.numel() for _, p in named)
+        obs_named = self.observer_named_parameters()
+        n_hot = sum(p.numel() for _, p in named)
+        n = n_hot + sum(p.numel() for _, p in obs_named)
         flat = torch.empty(n, dtype=torch.float32, device=dev)
         flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off, ranges, bucket = 0, [], 0
@@ -559,6 +583,13 @@ class VitaPolicy(nn.Module):
         while len(starts) < len(self.BUCKET_PREFIXES) + 1:
             starts.append(off)
         ranges = [(starts[i], starts[i + 1]) for i in range(len(self.BUCKET_PREFIXES))]
+        for _, p in obs_named:      # the observer's trainable tensors behind the hot path: same buffers, same fused optimizer
+            view = flat[off:off + p.numel()].view_as(p)
+            view.copy_(p.data)
+            p.data = view
+            p.grad = flat_grad[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self.observer_range = (n_hot, n) if n > n_hot else None
         self._flat, self._flat_grad, self.bucket_ranges = flat, flat_grad, ranges
         self._cache = {}
         return flat, flat_grad
@@ -663,20 +694,22 @@ class VitaPolicy(nn.Module):
         return t, pair_i, pair_j, enc_noise, fm_noise
 
     def loss_and_grads(self, batch, *, t=None, pair_i=None, pair_j=None, grad_ready_events=None, losses=None, enc_noise=None,
-                       fm_noise=None):
-        """Native training entry (no autograd): normalised batch -> losses (device float[8], _lib.LOSS_NAMES order), with
-        d loss / d parameter written into the parameters' .grad buffers.  No host synchronisation."""
+                       fm_noise=None, observer_event=None):
+        """Native training entry: normalised batch -> losses (device float[8], _lib.LOSS_NAMES order), with d loss / d parameter
+        written into the parameters' .grad buffers.  No host synchronisation.  With a trainable observer (observer='resnet18':
+        the reference trains the backbone in the same AdamW group, vita_policy.py:113-114, 222-229) the fused step also returns
+        d loss / d features and torch's backward of the observer alone turns it into the backbone's gradients, written into the
+        observer's range of the same flat buffer; `observer_event` (a torch.cuda.Event) is recorded behind it."""
         if self.inference_only:
             raise NotImplementedError(f"training with flow matcher '{self.config.policy.flow_matcher.name}' is not built "
                                       "(SURVEY.md 8(f) #4): only its sampler runs on the HIP path")
         if self.external_encoder or self.external_decoder:
             raise NotImplementedError("the native trainer (flat buffers, fused optimizer) has no external action encoder / decoder "
                                       "(transformer, cnn): train it through compute_loss(...).backward() with a torch optimizer (the drop-in path)")
-        obs_features = self.observer(batch)
-        if obs_features.requires_grad:
-            raise NotImplementedError("the native trainer (flat buffers, fused optimizer) does not carry gradients into a trainable observer "
-                                      "(observer='resnet18'): train it through compute_loss(...).backward() with policy.get_optimizer() (the "
-                                      "drop-in path), or run the observer under torch.no_grad() to keep it fixed")
+        obs_params = [p for _, p in self.observer_named_parameters()]
+        with torch.set_grad_enabled(bool(obs_params)):      # the observer's graph only; the hot path has its own backward
+            obs_features = self.observer(batch)
+        need_dobs = bool(obs_params) and obs_features.requires_grad
         actions = batch[self.config.task.action_key]
         pw, gw, gsd = self._train_handles()
         if self._flat_grad is None:
@@ -691,13 +724,34 @@ class VitaPolicy(nn.Module):
                 enc_noise = torch.randn(obs_features.shape[0], self.latent_dim, device=obs_features.device)
             elif not self.use_action_vae or not self.training:
                 enc_noise = None
-            return ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features, actions, t, r.to(torch.float32), grads=gw, losses=losses,
-                                             enc_noise=enc_noise, grad_ready_events=grad_ready_events)
-        t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features,
+            out = ops.compute_loss_meanflow(pw, self._mf_cfg, obs_features.detach(), actions, t, r.to(torch.float32), grads=gw, losses=losses,
+                                            enc_noise=enc_noise, grad_ready_events=grad_ready_events, need_dobs=need_dobs)
+            dobs = None
+            if need_dobs:
+                out, dobs = out
+            self._observer_backward(obs_features, dobs, obs_params, observer_event)
+            return out
+        t, pair_i, pair_j, enc_noise, fm_noise = self._draw(obs_features.shape[0], obs_features.device, t, pair_i, pair_j, obs_features.detach(),
                                                             actions, enc_noise, fm_noise)
-        out, _ = ops.compute_loss(pw, self._loss_cfg, obs_features, actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
-                                  grad_ready_events=grad_ready_events, losses=losses, enc_noise=enc_noise, fm_noise=fm_noise)
+        out, dobs = ops.compute_loss(pw, self._loss_cfg, obs_features.detach(), actions, t, grads=gw, pair_i=pair_i, pair_j=pair_j,
+                                     grad_ready_events=grad_ready_events, losses=losses, enc_noise=enc_noise, fm_noise=fm_noise,
+                                     need_dobs=need_dobs)
+        self._observer_backward(obs_features, dobs, obs_params, observer_event)
         return out
+
+    def _observer_backward(self, obs_features, dobs, obs_params, event):
+        """d loss / d features -> the observer's parameter gradients (torch autograd over the backbone alone), overwriting what the
+        buffers held: the native step's gradients are written, never accumulated."""
+        if dobs is not None:
+            if self._flat_grad is not None and getattr(self, "observer_range", None):
+                lo, hi = self.observer_range
+                self._flat_grad[lo:hi].zero_()          # autograd accumulates in place into the views
+            else:
+                for p in obs_params:
+                    p.grad = None
+            torch.autograd.backward(obs_features, dobs, inputs=obs_params)
+        if event is not None:
+            event.record(torch.cuda.current_stream(obs_features.device))
 
     def compute_loss(self, batch, *, t=None, pair_i=None, pair_j=None, enc_noise=None, fm_noise=None):
         """vita_policy.py:112-189.  Returns (loss, metrics) with the reference's metric keys; `loss` supports

@@ -45,6 +45,8 @@ class PolicyTrainer:
                                      rehearse=rehearse_collectives)
         self.overlap = overlap
         self.events = None
+        # a trainable observer's segment is the plan's last entry; its event is recorded by the policy, not by the fused step
+        self.observer_segment = getattr(policy, "observer_range", None) is not None
         if self.reducer.active:
             self.events = [torch.cuda.Event() for _ in range(1 + max(ev for _, _, ev in self.plan))]
             for e in self.events:   # torch creates the hipEvent_t lazily, on the first record: the C side needs the handle
@@ -78,8 +80,9 @@ class PolicyTrainer:
             net.train()
         batch = net.normalize_inputs(batch)
         batch = net.normalize_targets(batch)
-        net.loss_and_grads(batch, t=t, pair_i=pair_i, pair_j=pair_j, grad_ready_events=self.events if self.overlap else None,
-                           losses=self.losses)
+        ev = self.events if (self.events and self.overlap) else None
+        fused_ev, obs_ev = (ev[:-1], ev[-1]) if (ev and self.observer_segment) else (ev, None)
+        net.loss_and_grads(batch, t=t, pair_i=pair_i, pair_j=pair_j, grad_ready_events=fused_ev, losses=self.losses, observer_event=obs_ev)
         for i, (_, _, ev) in enumerate(self.plan):
             self.reducer.reduce(i, self.events[ev] if (self.events and self.overlap) else None)
         scale = self.reducer.finish()
@@ -111,7 +114,7 @@ class PolicyTrainer:
     def _flat_slices(self):
         """{id(parameter): (offset, numel)} of the hot-path parameters inside the flat buffers."""
         out, off = {}, 0
-        for _, p in self.network.hot_path_named_parameters():
+        for _, p in self.network.flat_named_parameters():
             out[id(p)] = (off, p.numel())
             off += p.numel()
         return out
@@ -225,7 +228,7 @@ class PolicyTrainer:
     def ema_state_dict(self) -> dict:
         """EMA weights under the reference's state-dict keys (what validate_online evaluates)."""
         out, off = {}, 0
-        for k, p in self.network.hot_path_named_parameters():
+        for k, p in self.network.flat_named_parameters():
             out[k] = self.ema[off:off + p.numel()].view_as(p)
             off += p.numel()
         return out
