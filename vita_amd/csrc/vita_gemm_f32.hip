@@ -414,19 +414,44 @@ static EpiParams epi_of(const vita_linear_args& a) {
 // split-K).  *taken = false: the call is not eligible and takes the fp32 kernels.
 static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool* taken) {
     *taken = false;
-    const Bf16Stage& st = bf16_stage();
+    Bf16Stage& st = bf16_stage();
+    // whatever happens below, this call overwrites a.Y: a bf16 copy of its old contents is stale from here on, and a pending
+    // emission request is for THIS output or for nobody
+    st.shadow_drop(a.Y);
+    uint16_t* emit_dst = (st.emit_y != nullptr && st.emit_y == a.Y) ? st.emit_dst : nullptr;
+    const int64_t emit_ld = st.emit_ld;
+    st.emit_y = nullptr;
     if (st.mode == 0 || st.ptr == nullptr || a.pro != VITA_PRO_NONE || a.M <= 0 || a.N <= 0 || a.K <= 0) return VITA_OK;
     if (st.mode == 1 && 2.0 * (double)a.M * (double)a.N * (double)a.K < kBf16MinFlops) return VITA_OK;
     const int Kp = (a.K + 7) & ~7;
     const size_t abytes = ((size_t)a.M * Kp * 2 + 255) & ~size_t(255), bbytes = ((size_t)a.N * Kp * 2 + 255) & ~size_t(255);
-    if (abytes + bbytes > st.bytes) return VITA_OK;
+    if (abytes + bbytes > st.bytes) return VITA_OK;      // (checked before the cache lookup: an uncached call needs both)
     VITA_REQUIRE(a.ldx >= (a.a_col ? a.M : a.K) && a.ldw >= (a.b_col ? a.N : a.K) && a.ldy >= a.N, "vita_linear (bf16 route): leading dimension too small");
     VITA_REQUIRE(a.act >= VITA_ACT_NONE && a.act <= VITA_ACT_MISH, "vita_linear (bf16 route): unknown activation %d", a.act);
     uint16_t* xa = static_cast<uint16_t*>(st.ptr);
     uint16_t* wb = reinterpret_cast<uint16_t*>(static_cast<char*>(st.ptr) + abytes);
-    if (a.a_col) VITA_TRY_RC(launch_pack_bf16_t(a.X, a.ldx, xa, Kp, a.K, a.M, stream));
+    // a weight the step packed once (Bf16Stage::wc): forward GEMMs read its row form, input-gradient GEMMs its transposed form
+    const uint16_t* wcached = nullptr;
+    if (!a.a_col) {
+        for (int i = 0; i < st.nwc && wcached == nullptr; ++i) {
+            const Bf16WEntry& e = st.wc[i];
+            if (e.w != a.W) continue;
+            if (!a.b_col && a.N == e.out_f && a.K == e.in_f && a.ldw == e.in_f) wcached = e.rows;
+            else if (a.b_col && a.N == e.in_f && a.K == e.out_f && a.ldw == e.in_f) wcached = e.t;
+        }
+    }
+    // the A operand's bf16 copy may already exist: written by the kernel that produced the fp32 matrix
+    const uint16_t* xshadow = nullptr;
+    if (!a.a_col) {
+        for (int i = 0; i < st.nsh; ++i)
+            if (st.sh[i].src == a.X && st.sh[i].ld == Kp && st.sh[i].rows >= a.M && st.sh[i].cols == a.K) { xshadow = st.sh[i].bf; break; }
+        if (xshadow != nullptr) st.shadow_drop(a.X);       // consumed
+    }
+    if (xshadow != nullptr) xa = const_cast<uint16_t*>(xshadow);
+    else if (a.a_col) VITA_TRY_RC(launch_pack_bf16_t(a.X, a.ldx, xa, Kp, a.K, a.M, stream));
     else VITA_TRY_RC(launch_pack_bf16(a.X, a.ldx, xa, Kp, a.M, a.K, stream));
-    if (a.b_col) VITA_TRY_RC(launch_pack_bf16_t(a.W, a.ldw, wb, Kp, a.K, a.N, stream));
+    if (wcached != nullptr) wb = const_cast<uint16_t*>(wcached);
+    else if (a.b_col) VITA_TRY_RC(launch_pack_bf16_t(a.W, a.ldw, wb, Kp, a.K, a.N, stream));
     else VITA_TRY_RC(launch_pack_bf16(a.W, a.ldw, wb, Kp, a.N, a.K, stream));
     vita_linear_args b = a;
     b.X = reinterpret_cast<const float*>(xa); b.ldx = Kp; b.W = reinterpret_cast<const float*>(wb); b.ldw = Kp; b.K = Kp;
@@ -435,8 +460,10 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
     vita_linear_args u = b;
     u.K = Kp / 2;                               // the kernel counts k in 4-byte units (bf16 pairs)
     const SplitK sk = plan_splitk(u);
-    VITA_TRY_RC(gemm_bf16_dma(b, nullptr, 0, stream, sk.splits > 1 ? &sk : nullptr));
+    const bool emit = emit_dst != nullptr && sk.splits <= 1 && emit_ld >= a.N && emit_ld % 8 == 0;   // a split GEMM's epilogue is the reduce pass
+    VITA_TRY_RC(gemm_bf16_dma(b, emit ? emit_dst : nullptr, emit ? emit_ld : 0, stream, sk.splits > 1 ? &sk : nullptr));
     if (sk.splits > 1) VITA_TRY_RC(launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream));
+    if (emit) st.shadow_add(a.Y, emit_dst, emit_ld, a.M, a.N);
     *taken = true;
     return VITA_OK;
 }

@@ -124,14 +124,37 @@ struct SplitkScope {
 // bf16-operand training GEMMs (vita_loss_config.gemm_bf16): inside the scope gemm_f32() stages both operands of an
 // eligible call as k-contiguous bf16 rows in `ptr` (stream-ordered reuse) and runs the bf16 LDS-DMA kernel; mode 1 only
 // for calls of at least kBf16MinFlops, mode 2 for every call without a LayerNorm prologue.
-struct Bf16Stage { void* ptr = nullptr; size_t bytes = 0; int mode = 0; };
+// wc: bf16 copies of the step's weights, packed ONCE per step (row form (out, r8(in)) for the forward GEMMs, transposed form
+// (in, r8(out)) for the input-gradient GEMMs) instead of once per GEMM call: a weight is an operand of 1 + K forward and 1 + K
+// input-gradient GEMMs of a step (round 3).
+struct Bf16WEntry { const float* w; const uint16_t* rows; const uint16_t* t; int out_f, in_f; };
+// shadows: bf16 row-major copies of fp32 activation matrices written by the kernel that PRODUCED them (a GEMM epilogue's ybf, the
+// LayerNorm kernel's bf16 output) instead of by a pack launch in front of the GEMM that consumes them.  emit_*: a request to the
+// next bf16-routed GEMM whose output is emit_y to write such a copy.  A shadow is dropped when it is consumed, when its fp32
+// source is overwritten by a routed GEMM, and at the end of the scope.
+struct Bf16Shadow { const float* src; const uint16_t* bf; int64_t ld; int rows, cols; };
+struct Bf16Stage {
+    void* ptr = nullptr; size_t bytes = 0; int mode = 0; Bf16WEntry wc[80]; int nwc = 0;
+    Bf16Shadow sh[4]; int nsh = 0;
+    const float* emit_y = nullptr; uint16_t* emit_dst = nullptr; int64_t emit_ld = 0;
+    uint16_t* arena = nullptr; size_t arena_halves = 0;      // shadow slots of the running step (vita_loss_step.hip)
+    void shadow_add(const float* src, const uint16_t* bf, int64_t ld, int rows, int cols) {
+        for (int i = 0; i < nsh; ++i)
+            if (sh[i].src == src) { sh[i] = Bf16Shadow{src, bf, ld, rows, cols}; return; }
+        if (nsh < 4) sh[nsh++] = Bf16Shadow{src, bf, ld, rows, cols};
+    }
+    void shadow_drop(const float* src) {
+        for (int i = 0; i < nsh; ++i)
+            if (sh[i].src == src) { sh[i] = sh[--nsh]; return; }
+    }
+};
 inline Bf16Stage& bf16_stage() {
     static thread_local Bf16Stage s;
     return s;
 }
 struct Bf16Scope {
     Bf16Stage saved;
-    Bf16Scope(void* p, size_t n, int mode) : saved(bf16_stage()) { bf16_stage().ptr = p; bf16_stage().bytes = n; bf16_stage().mode = mode; }
+    Bf16Scope(void* p, size_t n, int mode) : saved(bf16_stage()) { bf16_stage().ptr = p; bf16_stage().bytes = n; bf16_stage().mode = mode; bf16_stage().nwc = 0; bf16_stage().nsh = 0; bf16_stage().emit_y = nullptr; bf16_stage().arena = nullptr; bf16_stage().arena_halves = 0; }
     ~Bf16Scope() { bf16_stage() = saved; }
 };
 // Transposed copies of weights for the input-gradient GEMMs of a large-batch training step: dX = dY . W with W (out, in)

@@ -332,11 +332,34 @@ int time_path_bwd(const FlowCtx& c, const vita_flownet_weights& g, int T, float*
 int flow_trunk_fwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_mod) {
     const vita_flownet_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = M;
+    // bf16-operand step: the LayerNorm kernel and fc1's epilogue write the bf16 copies the next GEMM reads (Bf16Stage shadows)
+    // instead of a pack launch in front of it; only where both GEMMs of a layer take the bf16 route
+    Bf16Stage& bs = bf16_stage();
+    bs.nsh = 0;
+    const int H8 = (H + 7) & ~7, FF8 = (FF + 7) & ~7;
+    const bool sh = bs.mode != 0 && bs.arena != nullptr && (size_t)B * (H8 + FF8) <= bs.arena_halves &&
+                    (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops);
+    uint16_t* slot_hn = bs.arena;
+    uint16_t* slot_g = sh ? bs.arena + (size_t)B * H8 : nullptr;
     VITA_TRY(gemm_f32(lin(c.X(e), D, w->in_w, D, w->in_b, c.Hs(0, e), H, B, H, D, VITA_ACT_NONE), c.st));
     for (int l = 0; l < L; ++l) {
         const float* gamma = mod + (size_t)l * 3 * H;
         const float* scale = gamma + H;
         const float* shift = gamma + 2 * H;
+        if (sh) {
+            VITA_TRY(launch_ln_mod(c.Hs(l, e), H, c.HN(l, e), H, B, H, 1e-6f, VITA_PRO_LN_MOD, scale, ld_mod, shift, ld_mod, c.st, slot_hn, H8));
+            bs.shadow_add(c.HN(l, e), slot_hn, H8, B, H);
+            vita_linear_args a = lin(c.HN(l, e), H, w->fc1_w[l], H, w->fc1_b[l], c.G(l, e), FF, B, FF, H, VITA_ACT_GELU_TANH);
+            a.preact = c.U(l, e); a.ld_preact = FF;
+            bs.emit_y = c.G(l, e); bs.emit_dst = slot_g; bs.emit_ld = FF8;
+            VITA_TRY(gemm_f32(a, c.st));
+            vita_linear_args b = lin(c.G(l, e), FF, w->fc2_w[l], FF, w->fc2_b[l], c.Hs(l + 1, e), H, B, H, FF, VITA_ACT_NONE);
+            b.preact = c.Y2(l, e); b.ld_preact = H;
+            b.gate = gamma; b.ld_gate = ld_mod; b.resid = c.Hs(l, e); b.ld_resid = H;
+            VITA_TRY(gemm_f32(b, c.st));
+            bs.nsh = 0;
+            continue;
+        }
         // (the LayerNorm prologue of the few-row GEMM, vita_gemm_f32_small.hip, is not used here: with per-row modulation and the
         // normalised rows to be kept for the backward pass it measured no gain, B = 128 step 2.89 against 2.88 ms)
         VITA_TRY(launch_ln_mod(c.Hs(l, e), H, c.HN(l, e), H, B, H, 1e-6f, VITA_PRO_LN_MOD, scale, ld_mod, shift, ld_mod, c.st));
@@ -373,6 +396,11 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
     const vita_flownet_weights* w = c.w;
     const int D = w->D, H = w->H, FF = w->FF, L = w->L, B = M;
     const int64_t ldm = (int64_t)L * 3 * H;
+    Bf16Stage& bs = bf16_stage();      // as in flow_trunk_fwd: dU's bf16 copy comes out of the GEMM that makes dU
+    bs.nsh = 0;
+    const int FF8 = (FF + 7) & ~7;
+    const bool sh = bs.mode != 0 && bs.arena != nullptr && (size_t)B * FF8 <= bs.arena_halves &&
+                    (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops);
     VITA_TRY(gemm_f32(dgrad(c.DV(e), D, w->out_w, H, c.DHNF(e), H, B, H, D), c.st));
     VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(L, e), H, c.DHNF(e), H, w->norm_w, 0, B, H, 1e-5f, VITA_PRO_LN_AFFINE, c.DH0(e), H, 0,
                                              c.RN(e), nullptr, H, c.st));
@@ -384,8 +412,10 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
         VITA_TRY(vita_gate_bwd_f32(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st));
         vita_linear_args a = dgrad(c.Y2(l, e), H, w->fc2_w[l], FF, c.U(l, e), FF, B, FF, H);   // dU = (dY2 . W2) * gelu_tanh'(U)
         a.act = VITA_ACT_GELU_TANH; a.act_grad_z = c.U(l, e); a.ld_act_grad_z = FF;
+        if (sh) { bs.emit_y = c.U(l, e); bs.emit_dst = bs.arena; bs.emit_ld = FF8; }
         VITA_TRY(gemm_f32(a, c.st));
         VITA_TRY(gemm_f32(dgrad(c.U(l, e), FF, w->fc1_w[l], H, c.f.dhn, H, B, H, FF), c.st));
+        bs.nsh = 0;
         VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(l, e), H, c.f.dhn, H, scale, ld_mod, B, H, 1e-6f, VITA_PRO_LN_MOD, c.DH0(e), H, 1,
                                                  dmr + H, dmr + 2 * H, ldm, c.st));
     }
@@ -531,8 +561,39 @@ static int stage_wt(WtScope& sc, float* buf, const vita_flownet_weights* fl, con
     return rc;
 }
 
+// bf16 copies of every such weight, row form + transposed form, packed once per step (Bf16Stage::wc)
+static size_t wb_halves(const vita_flownet_weights* fl, const vita_decoder_weights& dec, const vita_encoder_weights& enc) {
+    size_t n = 0;
+    for_each_dgrad_weight(fl, nullptr, dec, enc, [&](const float*, int o, int i) {
+        n += (((size_t)o * ((i + 7) & ~7)) + 127) & ~size_t(127);
+        n += (((size_t)i * ((o + 7) & ~7)) + 127) & ~size_t(127);
+    });
+    return n;
+}
+static int stage_wb(uint16_t* buf, const vita_flownet_weights* fl, const vita_decoder_weights& dec, const vita_encoder_weights& enc, bool train,
+                    hipStream_t st) {
+    int rc = VITA_OK;
+    size_t off = 0;
+    Bf16Stage& bs = bf16_stage();
+    bs.nwc = 0;
+    for_each_dgrad_weight(fl, nullptr, dec, enc, [&](const float* w, int o, int i) {
+        uint16_t* rows = buf + off;
+        off += (((size_t)o * ((i + 7) & ~7)) + 127) & ~size_t(127);
+        uint16_t* t = buf + off;
+        off += (((size_t)i * ((o + 7) & ~7)) + 127) & ~size_t(127);
+        if (rc != VITA_OK || w == nullptr || bs.nwc >= 80) return;
+        // only what a bf16-routed call of this step will ask for: the forward form always, the transposed form with gradients
+        rc = launch_pack_bf16(w, i, rows, (i + 7) & ~7, o, i, st);
+        if (rc == VITA_OK && train) rc = launch_pack_bf16_t(w, i, t, (o + 7) & ~7, o, i, st);
+        bs.wc[bs.nwc++] = Bf16WEntry{w, rows, train ? t : nullptr, o, i};
+    });
+    return rc;
+}
+
 struct StepWs {
     float* wt;                        // transposed weights of the input-gradient GEMMs (train, B >= kWtMinRows)
+    uint16_t* wb;                     // bf16 copies of the weights (cfg.gemm_bf16, B >= kWtMinRows)
+    uint16_t* arena; size_t arena_halves;   // bf16 shadows of activations written by their producers (Bf16Stage)
     float *sk, *consts, *loss_part, *cs_part;
     float *sk_side[3], *cs_side[3];   // split-K / column-sum scratch of the side-stream branches
     float *z0, *ZZ, *dz0, *dZZ;       // ZZ = [pred; z1] (2B, D): the decoder's input rows
@@ -615,6 +676,11 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
         s.stage = c.take(s.stage_bytes / sizeof(float));
     }
     s.wt = (train && B >= (size_t)kWtMinRows) ? c.take(wt_floats(&w.flow, nullptr, w.dec, w.enc)) : nullptr;
+    s.wb = (cfg.gemm_bf16 && B >= (size_t)kWtMinRows) ? reinterpret_cast<uint16_t*>(c.take((wb_halves(&w.flow, w.dec, w.enc) + 1) / 2)) : nullptr;
+    if (cfg.gemm_bf16 && B >= (size_t)kWtMinRows) {      // (the same predicate as wb: when only measuring, every pointer is null)
+        s.arena_halves = 2 * B * ((((size_t)w.flow.H + 7) & ~size_t(7)) + (((size_t)w.flow.FF + 7) & ~size_t(7)));
+        s.arena = reinterpret_cast<uint16_t*>(c.take((s.arena_halves + 1) / 2));
+    }
     s.flow = carve_flow_train(c, w.flow, B, K, train);
     if (!cfg.external_decoder) s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
@@ -762,6 +828,10 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     hipStream_t st = (hipStream_t)stream;
     const bool train = grads != nullptr;
     StepWs s = carve_step(workspace, *w, *cfg, (size_t)B, true);
+    // the carve on the real base must be the carve that was measured (a region sized by a pointer test would not be: when measuring
+    // every pointer is null): refuse, rather than write past the workspace
+    VITA_REQUIRE(s.bytes <= workspace_bytes, "%s: internal error: the workspace carve (%zu bytes) exceeds the measured size (%zu)", who, s.bytes,
+                 workspace_bytes);
     const int D = w->flow.D, H = w->flow.H, L = w->flow.L, OUT = w->dec.OUT;
     const bool fe = cfg->freeze_encoder != 0, fd = cfg->freeze_decoder != 0;
     const bool do_sample = cfg->decode_flow_latents != 0 && !fe && !fd;                                                // :153
@@ -786,7 +856,9 @@ int vita_compute_loss_f32(const vita_policy_weights* w, const vita_policy_weight
     if (!no_fused) VITA_REQUIRE(skscope.enable_fused(st) == 0, "%s: could not zero the split-K counters", who);
     Bf16Scope bfscope(s.stage, s.stage_bytes, cfg->gemm_bf16);
     WtScope wtscope;
-    if (s.wt) VITA_TRY(stage_wt(wtscope, s.wt, &w->flow, nullptr, w->dec, w->enc, st));
+    if (s.wt && cfg->gemm_bf16 != 2) VITA_TRY(stage_wt(wtscope, s.wt, &w->flow, nullptr, w->dec, w->enc, st));
+    if (s.wb && !resume) VITA_TRY(stage_wb(s.wb, &w->flow, w->dec, w->enc, train, st));
+    bf16_stage().arena = s.arena; bf16_stage().arena_halves = s.arena_halves;
     // the bf16 staging region is reused call after call in stream order: one stream only in that mode
     Side* side = (train && B <= kSideMaxRows && cfg->gemm_bf16 == 0 && cfg->side_streams != 0) ? side_for_current_device() : nullptr;
     const bool vae = w->enc.variational != 0;
