@@ -51,9 +51,11 @@ struct FlowWs {
 // only on the step).  Needs every tile interior: B % 256 == 0 and 128-multiples for H, FF, D.  VITA_NO_LN_FOLD=1 disables.
 static bool use_ln_fold(const vita_flownet_weights* w, int B) {
     static const bool off = getenv("VITA_NO_LN_FOLD") != nullptr && atoi(getenv("VITA_NO_LN_FOLD")) != 0;
-    // below 3072 rows the fold's 64-row GEMMs (no split-K: a tile must own whole rows of the statistics) leave most CUs without a
-    // tile: B = 1024 2.85 ms folded against 1.85 ms unfolded, B = 2048 3.42 / 2.99, B = 3072 3.96 / 4.12
-    return !off && B >= 3072 && B % 256 == 0 && w->L >= 1 && w->H % 128 == 0 && w->H <= 2048 && w->FF % 128 == 0 && w->D % 128 == 0;
+    // round 2: below 3072 rows the fold's 64-row GEMMs (no split-K then) left most CUs without a tile (B = 1024 2.85 ms folded
+    // against 1.85 ms unfolded).  Round 3: they split K and a second pass applies the folded epilogue (gemm_f32_fold), so the
+    // fold starts at 1024 rows
+    static const int min_rows = getenv("VITA_LN_FOLD_MIN_ROWS") != nullptr ? atoi(getenv("VITA_LN_FOLD_MIN_ROWS")) : 1024;
+    return !off && B >= min_rows && B % 256 == 0 && w->L >= 1 && w->H % 128 == 0 && w->H <= 2048 && w->FF % 128 == 0 && w->D % 128 == 0;
 }
 // T = number of distinct timesteps (num_steps when sampling, B for per-row t); sampling: one modulation row per step serves the
 // whole batch (the Euler sampler), so the in-launch samplers' tables and hand-off state may be needed

@@ -356,6 +356,70 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(EpiParams e, const f
     }
 }
 
+// Second pass of a split-K GEMM that carries the folded-LayerNorm epilogue (vita_gemm_epilogue.h, EpiParams: producer fields aux_* /
+// stat_out, consumer fields ln_stats / ln_c1): sums the partials in split order and applies what the tile epilogue applies — the
+// consumer's finish rstd * (acc - mean * c1), bias, gate, residual, then the producer's aux = out * mul and the per-row, per-128-column
+// (mean, M2) — so the sampler's 64-row GEMMs can split K at batches where they would otherwise leave most CUs without a tile.
+// Layout: one thread per float4, N % 128 == 0: the 32 lanes of a half-wave hold one row's 128-column segment, as in the tile epilogue.
+// M * N / 4 must be a multiple of 256 (every lane of every wave active: the row statistics use DPP reductions).
+__global__ __launch_bounds__(256) void splitk_reduce_fold_kernel(EpiParams e, const float* __restrict__ part, int64_t ldp, int S) {
+    const int c4 = e.N / 4;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int row = (int)(i / c4), col = (int)(i - (int64_t)row * c4) * 4;
+    const int lane = threadIdx.x & 63;
+    const int64_t split_stride = (int64_t)e.M * ldp;
+    const float* src = part + (int64_t)row * ldp + col;
+    f32x4 a = *reinterpret_cast<const f32x4*>(src);
+    for (int s0 = 1; s0 < S; s0 += 8) {
+        f32x4 b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < S) b[u] = *reinterpret_cast<const f32x4*>(src + (int64_t)(s0 + u) * split_stride);
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (s0 + u < S) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = a[k] + b[u][k];
+            }
+    }
+    if (e.ln_stats) {      // consumer: finish the normalisation on the summed accumulators
+        float st2[2];
+        fold_row_stats(e, row, 128, st2);
+        const f32x4 c1 = *reinterpret_cast<const f32x4*>(e.ln_c1 + col);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = st2[1] * fmaf(-st2[0], c1[k], a[k]);
+    }
+    f32x4 bias = {0.f, 0.f, 0.f, 0.f}, g = {e.gate_scalar, e.gate_scalar, e.gate_scalar, e.gate_scalar}, rs = bias, out;
+    if (e.bias) bias = *reinterpret_cast<const f32x4*>(e.bias + col);
+    const bool has_gate = e.use_gate_scalar || (e.gate != nullptr);
+    if (e.gate) g = *reinterpret_cast<const f32x4*>(e.gate + (e.ld_gate ? (int64_t)row * e.ld_gate : 0) + col);
+    if (e.resid) rs = *reinterpret_cast<const f32x4*>(e.resid + (int64_t)row * e.ld_resid + col);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) out[k] = epi_elem<VITA_ACT_NONE, false>(a[k], bias[k], 0.f, g[k], has_gate, rs[k], e.resid != nullptr, nullptr);
+    *reinterpret_cast<f32x4*>(e.Y + (int64_t)row * e.ldy + col) = out;
+    if (e.aux_out != nullptr) {
+        f32x4 am = *reinterpret_cast<const f32x4*>(e.aux_mul + col);
+        if (e.aux_add_one) am = am + 1.0f;
+        *reinterpret_cast<f32x4*>(e.aux_out + (int64_t)row * e.ld_aux + col) = out * am;
+        // (mean, M2) of the row over its 128-column segment: the tile epilogue's shifted one-pass sums, in the same order
+        const float xa = __builtin_amdgcn_readlane(out[0], 0), xb = __builtin_amdgcn_readlane(out[0], 32);
+        const float x0 = lane < 32 ? xa : xb;
+        float sm = 0.f, q = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const float d = out[k] - x0; sm += d; q = fmaf(d, d, q); }
+        sm = half_wave_sum(sm);
+        q = half_wave_sum(q);
+        if ((lane & 31) == 0) {
+            const int64_t so = ((int64_t)(col / 128) * e.M + row) * 2;
+            e.stat_out[so] = x0 + sm * (1.0f / 128.0f);
+            e.stat_out[so + 1] = q - sm * sm * (1.0f / 128.0f);
+        }
+    }
+}
+static bool splitk_fold_ok(const vita_linear_args& a) {
+    return a.act == VITA_ACT_NONE && a.N % 128 == 0 && ((int64_t)a.M * (a.N / 4)) % 256 == 0 && a.preact == nullptr && a.act_grad_z == nullptr;
+}
+
 static int launch_splitk_reduce(const EpiParams& e, const float* part, int64_t ldp, int S, hipStream_t stream) {
     const int64_t n = (int64_t)e.M * ((e.N + 3) / 4);
     int blocks = (int)((n + 255) / 256);
@@ -509,7 +573,18 @@ int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t st
     VITA_REQUIRE(a.X && a.W && a.Y && !a.a_col && !a.b_col && a.pro == VITA_PRO_NONE && a.preact == nullptr && a.act_grad_z == nullptr &&
                      gemm_f32_dma_eligible(a),
                  "gemm_f32_fold: the call is not eligible for the folded-LayerNorm epilogue");
-    return gemm_f32_dma(a, stream, nullptr, &fold);
+    // few output tiles (the 64-row GEMMs below ~3072 rows): split the reduction over workgroups; the second pass applies the
+    // folded epilogue (round 3 -- before, the fold could not split K and started at 3072 rows)
+    const SplitK sk = splitk_fold_ok(a) ? plan_splitk(a) : SplitK{};
+    if (sk.splits <= 1 || fold.aux_bf != nullptr) return gemm_f32_dma(a, stream, nullptr, &fold);   // (the second pass has no bf16 output)
+    VITA_TRY_RC(gemm_f32_dma(a, stream, &sk, &fold));
+    EpiParams e = epi_of(a);
+    e.aux_out = fold.aux_out; e.ld_aux = fold.ld_aux; e.aux_mul = fold.aux_mul; e.aux_add_one = fold.aux_add_one;
+    e.stat_out = fold.stat_out; e.ln_stats = fold.ln_stats; e.ln_c1 = fold.ln_c1; e.ln_nseg = fold.ln_nseg; e.ln_fold_eps = fold.ln_fold_eps;
+    const int64_t n = (int64_t)a.M * (a.N / 4);
+    hipLaunchKernelGGL(splitk_reduce_fold_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, stream, e, sk.partial, sk.ld_partial, sk.splits);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
 }
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {

@@ -152,7 +152,7 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
     p.epi.vec = epi_vec_ok(p.epi);
     if (fold) {
         auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
-        VITA_REQUIRE(p.epi.vec && a.M % 256 == 0 && a.N % 128 == 0 && sk == nullptr && al(fold->aux_out) && al(fold->aux_mul) &&
+        VITA_REQUIRE(p.epi.vec && a.M % 256 == 0 && a.N % 128 == 0 && al(fold->aux_out) && al(fold->aux_mul) &&
                          al(fold->ln_c1) && fold->ld_aux % 4 == 0,
                      "folded LayerNorm epilogue needs interior, 16-byte aligned tiles (M=%d N=%d)", a.M, a.N);
         VITA_REQUIRE((fold->aux_out == nullptr) == (fold->stat_out == nullptr) && (fold->aux_out == nullptr) == (fold->aux_mul == nullptr) &&
@@ -185,9 +185,9 @@ int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk
 #ifdef VITA_LAB_KG      // lab: the k-group count of the 64-row tile for short reductions
     if (a.K <= 512 && (long)((a.M + 255) / 256) * ((a.N + 127) / 128) < 256) return launch_dma<64, 128, 64, 3, 2, VITA_LAB_KG>(p, stream);
 #endif
-    if (fold == nullptr && (sk == nullptr || sk->splits <= 1)) {
-        // (calls with the folded-LayerNorm epilogue keep the rule below: the persistent sampler walks the same tiles and must give
-        // the same bits, tests/test_gpu_persistent.py)
+    if ((fold == nullptr || a.M % 4096 != 0) && (sk == nullptr || sk->splits <= 1)) {
+        // (calls with the folded-LayerNorm epilogue at the batches the persistent sampler takes -- multiples of 4096 rows -- keep the
+        // rule below: it walks the same tiles and must give the same bits, tests/test_gpu_persistent.py)
         // One workgroup per CU at a time: a launch costs ceil(tiles / 256) rounds of its tile's time.  Tile times relative to the
         // 64-row tile, from the stand-alone kernels at 4096 rows (25.7 / 45 / 83 us per round): 1, 1.8, 3.4.  B = 4096: 256-row tiles
         // (one round); 2048: 128-row (one round instead of two 64-row ones: sampler 2.99 -> 2.87 ms); 3072: 64-row (three rounds
