@@ -162,3 +162,74 @@ def test_rccl_branch_one_rank_rehearsal_equals_the_plain_trainer():
     torch.cuda.synchronize()
     assert torch.equal(p0, tr.flat.cpu()) and torch.equal(e0, tr.ema.cpu())
     assert gn0 == tr.metrics()["grad_norm"]
+
+
+def _obs_setup():
+    """pusht dims with the ResNet18 observer on 96 x 96 frames (tests/test_gpu_observer.py's policy), a batch of 8."""
+    from vita_amd.config import default_config
+    from vita_amd.policy import VitaPolicy
+    cfg = default_config("pusht")
+    cfg.policy.vita.latent_dim = 64
+    cfg.policy.action_ae.net.merge({"latent_dim": 64, "enc_hidden_dim": 48, "dec_hidden_dim": 48, "num_layers": 4})
+    cfg.policy.flow_net.merge({"hidden_dim": 64, "num_layers": 2})
+    cfg.policy.flow_matcher.name = "conditional"
+    cfg.scheduler_name = "constant"
+    cfg.optimizer_lr = 1e-3
+    cfg.optimizer_eps = 1e-3
+    s, a, cam = cfg.task.state_dim, cfg.task.action_dim, cfg.task.image_keys[0]
+    stats = {cfg.task.state_key: {"mean": [0.1] * s, "std": [1.5] * s}, cfg.task.action_key: {"mean": [0.0] * a, "std": [2.0] * a},
+             cam: {"mean": [[[0.485]], [[0.456]], [[0.406]]], "std": [[[0.229]], [[0.224]], [[0.225]]]}}
+    torch.manual_seed(0)
+    pol = VitaPolicy(cfg, stats, observer="resnet18")
+    g = torch.Generator().manual_seed(3)
+    batch = {cfg.task.state_key: torch.randn(8, 1, s, generator=g), cam: torch.rand(8, 1, 3, 96, 96, generator=g),
+             cfg.task.action_key: torch.randn(8, 16, a, generator=g)}
+    return cfg, pol, batch, torch.rand(8, generator=g)
+
+
+def _obs_steps(tr, batch, t, dev):
+    for step in range(2):
+        torch.manual_seed(40 + step)            # the observer's crop draw
+        tr.train_step(batch, t=t.to(dev))
+    torch.cuda.synchronize()
+    return tr.flat.cpu(), tr.metrics()["grad_norm"]
+
+
+def _rccl_observer_worker(rank, port, out):
+    import torch.distributed as dist
+    from vita_amd.trainer import PolicyTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg, pol, batch, t = _obs_setup()
+        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100, rehearse_collectives=True)
+        assert tr.reducer.active and tr.observer_segment and tr.plan[-1][:2] == pol.observer_range
+        assert len(tr.events) == 4 + cfg.policy.flow_net.num_layers + 1      # the fused step's events + the observer's
+        out["obs"] = _obs_steps(tr, batch, t, dev)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_rehearsal_with_a_trainable_observer():
+    """The data-parallel step with the ResNet18 observer in the flat buffers: the fused step's 4 + L events, then the observer's
+    segment behind torch's backward of the backbone (its event recorded by the policy), all-reduced on the side stream in a
+    one-rank RCCL group.  Against the trainer without a process group (MIOpen's weight gradients are not run-to-run bitwise:
+    2e-4 on the parameters after two steps)."""
+    from vita_amd.trainer import PolicyTrainer
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.start_processes(_rccl_observer_worker, args=(_free_port(), out), nprocs=1, join=True, start_method="spawn")
+    p0, gn0 = out["obs"]
+    mgr.shutdown()
+    cfg, pol, batch, t = _obs_setup()
+    tr = PolicyTrainer(cfg, pol, "cuda:0", num_training_steps=100)
+    ref, gn = _obs_steps(tr, batch, t, "cuda:0")
+    err = ((p0 - ref).abs().max() / ref.abs().max()).item()
+    assert err <= 2e-4, err
+    assert abs(gn0 - gn) <= 1e-3 * gn
