@@ -630,6 +630,9 @@ typedef struct vita_meanflow_loss_config {
     float temperature;            /* <= 0: 0.07, the default of compute_contrastive_loss (contrastive_loss.py:5) */
     float kl_weight;              /* variational encoder (w->enc.variational): action_kl_weight, vita_policy.py:146-150; `enc_noise` (B, D) is
                                      the posterior's standard-normal draw, NULL = deterministic posterior (z = mean, KL = 0) */
+    int32_t grad_ready_layers;    /* 1: `grad_ready` holds 4 + L events (round 3), recorded in the order [0] decoder, [3 + l] hidden layer l's
+                                     two Linears (l = 0 first), [1] the time / interval embeddings, [3 + L] input layer + u / v heads,
+                                     [2] encoders + obs_encoder (+ d_obs_features); 0: three events, [0] decoder, [1] flow net, [2] everything */
 } vita_meanflow_loss_config;
 /* losses of the MeanFlow step: device float[VITA_MF_LOSS_COUNT] */
 enum { VITA_MF_LOSS_TOTAL = 0, VITA_MF_LOSS_FLOW = 1 /* meanflow_loss, or imf_loss + aux_v_loss_weight * aux_v_loss */,

@@ -233,3 +233,65 @@ def test_rccl_rehearsal_with_a_trainable_observer():
     err = ((p0 - ref).abs().max() / ref.abs().max()).item()
     assert err <= 2e-4, err
     assert abs(gn0 - gn) <= 1e-3 * gn
+
+
+def _mf_setup():
+    cfg = _cfg()
+    cfg.policy.flow_matcher.name = "mean"
+    cfg.policy.flow_net.name = "simple_mean_flow_net"
+    cfg.policy.flow_matcher.num_sampling_steps = 2
+    pol = _policy(cfg)
+    with torch.no_grad():      # the reference zero-initialises the MeanFlow heads: give them values
+        for k, p in pol.named_parameters():
+            if "output_layer" in k:
+                p.copy_(0.1 * torch.randn(p.shape, generator=torch.Generator().manual_seed(3)))
+    return cfg, pol
+
+
+def _mf_steps(tr, cfg, dev):
+    g = torch.Generator().manual_seed(11)
+    for batch, t in _batches(cfg, B, STEPS):
+        r = t * torch.rand(B, generator=g)
+        tr.train_step(batch, t=t.to(dev), pair_i=r.to(dev))
+    torch.cuda.synchronize()
+    return tr.flat.cpu(), tr.ema.cpu(), tr.metrics()["grad_norm"]
+
+
+def _rccl_meanflow_worker(rank, port, out):
+    import torch.distributed as dist
+    from vita_amd.trainer import PolicyTrainer
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg, pol = _mf_setup()
+        tr = PolicyTrainer(cfg, pol, dev, num_training_steps=100, max_bucket_elems=20000, rehearse_collectives=True)
+        L_ = cfg.policy.flow_net.num_layers
+        assert tr.reducer.active and len(tr.events) == 4 + L_                     # per-layer events for the MeanFlow step too
+        assert [ev for _, _, ev in tr.plan] == [0] + [3 + l for l in range(L_)] + [1, 3 + L_, 2]   # the order they fire in
+        assert tr.plan[0][0] == 0 and sorted((lo, hi) for lo, hi, _ in tr.plan)[-1][1] == tr.flat.numel()
+        out["mf"] = _mf_steps(tr, cfg, dev)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_rccl_rehearsal_of_the_meanflow_step_with_per_layer_events():
+    """vita_meanflow_loss_config.grad_ready_layers (round 3): the MeanFlow step records 4 + L events — decoder, each hidden layer,
+    the time / interval embeddings, input layer + heads, encoders — and the reducer all-reduces one contiguous segment behind each.
+    One-rank RCCL group: three steps must leave exactly the parameters of the trainer without a process group (which passes no
+    events and runs the weight gradients in the single-event order)."""
+    from vita_amd.trainer import PolicyTrainer
+    ctx = mp.get_context("spawn")
+    mgr = ctx.Manager()
+    out = mgr.dict()
+    mp.start_processes(_rccl_meanflow_worker, args=(_free_port(), out), nprocs=1, join=True, start_method="spawn")
+    p0, e0, gn0 = out["mf"]
+    mgr.shutdown()
+    cfg, pol = _mf_setup()
+    tr = PolicyTrainer(cfg, pol, "cuda:0", num_training_steps=100)
+    p1, e1, gn1 = _mf_steps(tr, cfg, "cuda:0")
+    assert torch.equal(p0, p1) and torch.equal(e0, e1) and gn0 == gn1

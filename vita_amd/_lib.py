@@ -127,7 +127,7 @@ class MeanFlowLossConfig(C.Structure):
         ("dispersive_loss_weight", C.c_float), ("dispersive_loss_tau", C.c_float),
         ("freeze_encoder", C.c_int32), ("freeze_decoder", C.c_int32),
         ("enc_contrastive_weight", C.c_float), ("flow_contrastive_weight", C.c_float), ("temperature", C.c_float),
-        ("kl_weight", C.c_float),
+        ("kl_weight", C.c_float), ("grad_ready_layers", C.c_int32),
     ]
 
 

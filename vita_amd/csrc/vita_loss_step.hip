@@ -1761,17 +1761,14 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     // z_t = t*x0 + (1-t)*x1 (v is detached): d x1 += (1-t) d z_t, d x0 += t d z_t
     VITA_TRY(vita_cfm_interpolate_bwd_f32(s.dzt, nullptr, t, nullptr, nullptr, dz1, s.dz0, B, D, 1, st));
     if (nce_enc || nce_flow) VITA_TRY(launch_axpy(s.dz0c, s.dz0, (int64_t)B * D, st));
-    // weight gradients over the stacked E*B rows
-    {
-        const int R = Eg * B;      // the forward-only slot of improved MeanFlow carries no gradient
+    // weight gradients over the stacked E*B rows.  With cfg->grad_ready_layers the sections are ordered for a data-parallel caller's
+    // link as in vita_compute_loss_f32: the hidden layers first (one event each: the bulk of the gradient bytes), then the time /
+    // interval embeddings (event 1), the input layer and the heads (event 3 + L); the encoders follow (event 2)
+    const bool per_layer = cfg->grad_ready_layers != 0 && grad_ready != nullptr;
+    const int R = Eg * B;      // the forward-only slot of improved MeanFlow carries no gradient
+    auto outer_wgrads = [&]() -> int {
         VITA_TRY(gemm_f32(wgrad(s.DU, D, mc.Xs(L, 0), H, mut(gf.u_w), H, R, H, D), st));
         VITA_TRY(vita_colsum_f32(s.DU, D, R, D, s.cs_part, mut(gf.u_b), 0, st));
-        for (int l = 0; l < L; ++l) {
-            VITA_TRY(gemm_f32(wgrad(mc.DX(l + 1, 0), H, mc.S(l, 0), FF, mut(gf.fc2_w[l]), FF, R, FF, H), st));
-            VITA_TRY(vita_colsum_f32(mc.DX(l + 1, 0), H, R, H, s.cs_part, mut(gf.fc2_b[l]), 0, st));
-            VITA_TRY(gemm_f32(wgrad(mc.U1(l, 0), FF, mc.Xc(l, 0), H, mut(gf.fc1_w[l]), H, R, H, FF), st));
-            VITA_TRY(vita_colsum_f32(mc.U1(l, 0), FF, R, FF, s.cs_part, mut(gf.fc1_b[l]), 0, st));
-        }
         VITA_TRY(gemm_f32(wgrad(mc.DX(0, 0), H, s.X0, D, mut(gf.in_w), D, R, D, H), st));
         VITA_TRY(vita_colsum_f32(mc.DX(0, 0), H, R, H, s.cs_part, mut(gf.in_b), 0, st));
         if (imf) {      // the v head is used by evaluation 0 only
@@ -1781,6 +1778,15 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
             if (gf.v_w) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_w), 0, (size_t)D * H * 4, st));
             if (gf.v_b) VITA_CHECK_HIP(hipMemsetAsync(mut(gf.v_b), 0, (size_t)D * 4, st));
         }
+        return VITA_OK;
+    };
+    if (!per_layer) VITA_TRY(outer_wgrads());
+    for (int l = 0; l < L; ++l) {
+        VITA_TRY(gemm_f32(wgrad(mc.DX(l + 1, 0), H, mc.S(l, 0), FF, mut(gf.fc2_w[l]), FF, R, FF, H), st));
+        VITA_TRY(vita_colsum_f32(mc.DX(l + 1, 0), H, R, H, s.cs_part, mut(gf.fc2_b[l]), 0, st));
+        VITA_TRY(gemm_f32(wgrad(mc.U1(l, 0), FF, mc.Xc(l, 0), H, mut(gf.fc1_w[l]), H, R, H, FF), st));
+        VITA_TRY(vita_colsum_f32(mc.U1(l, 0), FF, R, FF, s.cs_part, mut(gf.fc1_b[l]), 0, st));
+        if (per_layer) VITA_TRY(record(3 + l));
     }
     // conditioning path: tc = t2(silu(t1 t)) + h2(silu(h1 h)) over the T rows
     {
@@ -1798,6 +1804,10 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
         }
     }
     VITA_TRY(record(1));
+    if (per_layer) {
+        VITA_TRY(outer_wgrads());
+        VITA_TRY(record(3 + L));
+    }
     // encoders
     {
         StepWs es{};

@@ -1226,12 +1226,18 @@ def compute_loss_meanflow(pw: MeanFlowPolicyHandle, cfg, obs_features: Tensor, a
     ws = workspace(dev, nbytes)
     if need_dobs and grads is None:
         raise L.VitaHipError("compute_loss_meanflow: need_dobs needs grads")
+    ev = _event_handles(grad_ready_events, "compute_loss_meanflow")
+    if ev is not None and len(ev) > 3:      # 4 + L events: per-section readiness (vita_meanflow_loss_config.grad_ready_layers)
+        if len(ev) != 4 + pw.w.flow.L:
+            raise L.VitaHipError(f"compute_loss_meanflow: {len(ev)} grad_ready events; pass 3, or 4 + L = {4 + pw.w.flow.L}")
+        cfg = L.MeanFlowLossConfig.from_buffer_copy(cfg)
+        cfg.grad_ready_layers = 1
     dobs = torch.empty_like(obs_features) if need_dobs else None
     L.check(lib.vita_compute_loss_meanflow_f32(C.byref(pw.w), C.byref(grads.w) if grads is not None else None, C.byref(cfg),
                                                obs_features.data_ptr(), _ld(obs_features), actions.data_ptr(), t.data_ptr(), r.data_ptr(),
                                                enc_noise.data_ptr() if enc_noise is not None else None, B, losses.data_ptr(),
                                                dobs.data_ptr() if dobs is not None else None, _ld(dobs) if dobs is not None else 0,
-                                               _event_handles(grad_ready_events[:3] if grad_ready_events else None, "compute_loss_meanflow"),
+                                               ev,
                                                ws.data_ptr(), ws.numel(), _stream(obs_features)),
             "vita_compute_loss_meanflow_f32")
     return (losses, dobs) if need_dobs else losses

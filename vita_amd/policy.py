@@ -488,8 +488,14 @@ class VitaPolicy(nn.Module):
         layers.l.mlp.*, 3 + L for the outer projections and the final norm, 1 for the time path (time_embed, time_modulator);
         1 for everything else and for the MeanFlow net (its step records events 0..2)."""
         parts = key.split(".")
-        if self.mean_flow or parts[0] != "flow_net":
+        if parts[0] != "flow_net":
             return 1
+        if self.mean_flow:      # vita_meanflow_loss_config.grad_ready_layers: hidden_layers.l -> 3 + l, embeddings -> 1, input layer / heads -> 3 + L
+            if parts[1] == "hidden_layers":
+                return 3 + int(parts[2])
+            if parts[1] in ("t_embed", "h_embed"):
+                return 1
+            return 3 + int(self.config.policy.flow_net.num_layers)
         if len(parts) > 3 and parts[1] == "layers" and parts[3] == "mlp":
             return 3 + int(parts[2])
         if parts[1] in ("input_proj", "norm", "out_proj"):
@@ -530,7 +536,7 @@ class VitaPolicy(nn.Module):
         (vita_loss_config.grad_ready_layers): the decoder (event 0); each layer's mlp.fc1 / mlp.fc2 gradients (event 3 + l, their
         stacked weight-gradient GEMMs run layer by layer); the encoders (event 2); the time path and the modulators (event 1); the
         outer projections and the final norm (event 3 + L) — most gradient bytes per unit of compute first, 2 MB last.  The
-        MeanFlow step records events 0, 1, 2 in that order."""
+        MeanFlow step (round 3) records 0, 3 .. 3+L-1 (hidden layers), 1 (time / interval embeddings), 3+L (input layer, heads), 2."""
         plan, off = [], 0
         named = self.hot_path_named_parameters()
         for k, p in named:
@@ -548,7 +554,10 @@ class VitaPolicy(nn.Module):
             off += n
         # 4 + L events fire 0, 3 .. 3+L-1, 2, 1, 3+L; 3 events only: 0, 1, 2
         last = max(ev for _, _, ev in plan)
-        order = {0: -1, 2: last - 0.6, 1: last - 0.3} if last >= 3 else {}
+        if self.mean_flow:      # fires 0, 3 .. 3+L-1, 1, 3+L, 2 (the encoders last)
+            order = {0: -1, 1: last - 0.5, 2: last + 1}
+        else:
+            order = {0: -1, 2: last - 0.6, 1: last - 0.3} if last >= 3 else {}
         plan.sort(key=lambda seg: (order.get(seg[2], seg[2]), seg[0]))
         n_obs = sum(p.numel() for _, p in self.observer_named_parameters())
         if n_obs:       # the observer's gradients are final last: torch's backward of the backbone runs behind the fused step,
