@@ -524,6 +524,15 @@ int vita_pack_bf16_f32(const float* src, int64_t ld_src, uint16_t* dst, int64_t 
  * vita_linear_f32 except the LayerNorm prologue and transposed operands. */
 int vita_linear_bf16(const vita_linear_args* args, uint16_t* y_bf16, int64_t ld_ybf, vita_stream_t stream);
 
+/* C (M, N) fp32 = A^T . B for ROW-MAJOR bf16 A (R, lda >= M) and B (R, ldb >= N): the weight gradient dW = dY^T X of F.linear
+ * (reference flow net, simple_flow_net.py:27-47, under torch.autograd) read from the bf16 copies of dY and X as they lie in
+ * memory -- no transposed operand copies; the fragments are transposed on their way out of LDS (ds_read_b64_tr_b16).
+ * M, N, lda, ldb multiples of 8, 16-byte aligned rows.  splitk_ws: NULL, or vita_splitk_workspace_bytes() of 256-byte aligned
+ * scratch: the reduction over R is then split over workgroups and summed in a fixed order (deterministic).
+ * fp32 accumulation of bf16 products: tests/test_gpu_bf16.py states the tolerance (1e-3 of the result's scale). */
+int vita_linear_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N, int32_t R,
+                        void* splitk_ws, size_t splitk_ws_bytes, vita_stream_t stream);
+
 typedef struct vita_bf16_weights { /* vita_pack_bf16_f32 copies of the GEMM weights, row stride = (K + 7) & ~7 */
     const uint16_t* obs_w;                                            /* obs_encoder.weight */
     const uint16_t *in_w, *out_w;                                     /* flow_net.input_proj / out_proj */

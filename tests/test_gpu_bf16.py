@@ -53,6 +53,42 @@ def test_linear_bf16_matches_fp64_on_the_rounded_operands(ops, M, N, K):
     assert torch.equal(y, y2)
 
 
+@pytest.mark.parametrize("R,M,N,split", [(32, 8, 8, False), (100, 136, 72, False), (1000, 336, 512, True), (4096, 2048, 512, True),
+                                         (28672, 512, 2048, True), (777, 128, 128, True), (5000, 512, 512, False)])
+def test_linear_bf16_tn_matches_fp64_on_the_rounded_operands(ops, R, M, N, split):
+    """dW = dY^T X from row-major bf16 operands (transposed LDS reads): ragged R (not a multiple of the 32-row k-tile), ragged
+    M / N (multiples of 8 only), with and without the split over R.  Asymmetric random operands; tolerance 2e-6 of the result's
+    scale (fp32 accumulation: only the summation order differs from fp64)."""
+    g = torch.Generator().manual_seed(R + M + N)
+    a = torch.randn(R, M, generator=g).to(DEV)
+    b = (torch.randn(R, N, generator=g) * 0.5 + 0.1).to(DEV)
+    ab, bb = ops.pack_bf16(a), ops.pack_bf16(b)
+    c = ops.linear_bf16_tn(ab, bb, M, N, split=split)
+    ref = bf16_round(a.cpu()).T @ bf16_round(b.cpu())
+    assert c.shape == (M, N)
+    assert nerr(c, ref) < 2e-6
+    # a second call on the same operands: deterministic to the bit
+    assert torch.equal(c, ops.linear_bf16_tn(ab, bb, M, N, split=split))
+
+
+def test_linear_bf16_tn_reads_operands_inside_wider_rows(ops):
+    """Operands that are column blocks of wider matrices (lda > M): the stacked activation buffers of the training step."""
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(640, 256, generator=g).to(DEV)
+    b = torch.randn(640, 384, generator=g).to(DEV)
+    ab, bb = ops.pack_bf16(a), ops.pack_bf16(b)
+    c = ops.linear_bf16_tn(ab[:, 64:192], bb[:, 128:256], 128, 128)
+    ref = bf16_round(a.cpu())[:, 64:192].T @ bf16_round(b.cpu())[:, 128:256]
+    assert nerr(c, ref) < 2e-6
+
+
+def test_linear_bf16_tn_rejects_ragged_widths(ops):
+    from vita_amd import _lib as L
+    ab = torch.zeros(64, 16, dtype=torch.int16, device=DEV)
+    with pytest.raises(L.VitaHipError):
+        ops.linear_bf16_tn(ab, ab, 12, 16)
+
+
 def test_linear_bf16_rejects_unpacked_operands(ops):
     from vita_amd._lib import VitaHipError
     import ctypes as C

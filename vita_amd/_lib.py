@@ -224,6 +224,7 @@ SIGNATURES = {
                                           C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32, C.c_double, c_fp]),
     "vita_pack_bf16_f32": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, C.c_int64, C.c_int32, c_fp]),
     "vita_linear_bf16": (C.c_int, [C.POINTER(LinearArgs), c_fp, C.c_int64, c_fp]),
+    "vita_linear_bf16_tn": (C.c_int, [c_fp, C.c_int64, c_fp, C.c_int64, c_fp, C.c_int64, C.c_int32, C.c_int32, C.c_int32, c_fp, C.c_size_t, c_fp]),
     "vita_generate_actions_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights), C.c_int32,
                                                                 C.c_int32, C.c_int32]),
     "vita_generate_actions_bf16": (C.c_int, [c_fp, C.c_int32, C.POINTER(FlowNetWeights), C.POINTER(DecoderWeights),

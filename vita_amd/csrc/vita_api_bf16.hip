@@ -202,6 +202,20 @@ int vita_linear_bf16(const vita_linear_args* a, uint16_t* y_bf16, int64_t ld_ybf
     return gemm_bf16_dma(*a, y_bf16, ld_ybf, (hipStream_t)stream);
 }
 
+int vita_linear_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int32_t M, int32_t N, int32_t R,
+                        void* splitk_ws, size_t splitk_ws_bytes, vita_stream_t stream) {
+    const char* who = "vita_linear_bf16_tn";
+    VITA_REQUIRE(A && B && C, "%s: null argument", who);
+    VITA_REQUIRE(M > 0 && N > 0 && R > 0 && ldc >= N, "%s: bad shape M=%d N=%d R=%d ldc=%lld", who, M, N, R, (long long)ldc);
+    VITA_REQUIRE(gemm_bf16_tn_eligible(A, lda, B, ldb, M, N, R),
+                 "%s: operands must be 16-byte aligned bf16 rows with lda >= M, ldb >= N multiples of 8, and M, N multiples of 8", who);
+    VITA_REQUIRE(splitk_ws == nullptr || (reinterpret_cast<uintptr_t>(splitk_ws) & 255u) == 0, "%s: splitk_ws must be 256-byte aligned", who);
+    vita_linear_args a{};
+    a.Y = C; a.ldy = ldc; a.M = M; a.N = N; a.K = R; a.act = VITA_ACT_NONE;
+    a.splitk_ws = splitk_ws; a.splitk_ws_bytes = splitk_ws_bytes;
+    return gemm_bf16_wgrad_tn(A, lda, B, ldb, a, (hipStream_t)stream);
+}
+
 size_t vita_generate_actions_bf16_workspace_bytes(const vita_flownet_weights* fw, const vita_decoder_weights* dw, int32_t O, int32_t B,
                                                   int32_t num_steps) {
     if (!fw || !dw || B <= 0 || num_steps <= 0 || O <= 0) return 0;

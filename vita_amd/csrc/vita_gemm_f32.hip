@@ -473,6 +473,34 @@ static EpiParams epi_of(const vita_linear_args& a) {
     return e;
 }
 
+// dW = dY^T X from ROW-MAJOR bf16 copies of dY (R, M) and X (R, N) (vita_gemm_bf16_tn.hip): the reduction over the R stacked rows
+// is split over workgroups until ~2 workgroups per CU are in flight, then summed by the deterministic second pass.
+// a = wgrad(...) of the fp32 call: Y / ldy / M / N / K = R and the split-K scratch; a.X / a.W are not read.
+int gemm_bf16_wgrad_tn(const uint16_t* dYb, int64_t ld_dy, const uint16_t* Xb, int64_t ldx, const vita_linear_args& a, hipStream_t stream) {
+    SplitK sk;
+    const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (a.splitk_ws != nullptr && (reinterpret_cast<uintptr_t>(a.splitk_ws) & 255u) == 0 && tiles < 512) {
+        long S = (512 + tiles - 1) / tiles;
+        const long by_r = a.K / 256;                       // at least 8 k-tiles of 32 rows per split
+        if (S > by_r) S = by_r;
+        const int64_t ldp = ((int64_t)a.N + 3) & ~int64_t(3);
+        const long by_ws = (long)(a.splitk_ws_bytes / ((size_t)a.M * ldp * sizeof(float)));
+        if (S > by_ws) S = by_ws;
+        if (S >= 2) {
+            int rps = (int)((a.K + S - 1) / S);
+            rps = (rps + 31) & ~31;
+            sk.splits = (a.K + rps - 1) / rps;
+            sk.k_per_split = rps;
+            sk.partial = static_cast<float*>(a.splitk_ws);
+            sk.ld_partial = ldp;
+            if (sk.splits < 2) sk.splits = 1;
+        }
+    }
+    VITA_TRY_RC(gemm_bf16_tn(dYb, ld_dy, Xb, ldx, a, stream, sk.splits > 1 ? &sk : nullptr));
+    if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
+    return VITA_OK;
+}
+
 // bf16-operand route (training step with vita_loss_config.gemm_bf16): stage A(m,k) and B(n,k) as bf16 rows (transposing
 // column operands), run the bf16 LDS-DMA kernel with the call's own epilogue (incl. act'(z) of the backward GEMMs and
 // split-K).  *taken = false: the call is not eligible and takes the fp32 kernels.

@@ -60,6 +60,11 @@ int launch_ln_mod(const float* x, int64_t ldx, float* y, int64_t ldy, int M, int
 struct SplitK;
 int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipStream_t stream, const SplitK* sk = nullptr,
                   const EpiFold* fold = nullptr);
+// C (M, N) = A^T B for row-major bf16 A (R, M), B (R, N): the weight-gradient GEMM without transposed operand copies
+// (vita_gemm_bf16_tn.hip); gemm_bf16_wgrad_tn plans the split over R and runs the second pass (vita_gemm_f32.hip)
+bool gemm_bf16_tn_eligible(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int R);
+int gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
+int gemm_bf16_wgrad_tn(const uint16_t* dYb, int64_t ld_dy, const uint16_t* Xb, int64_t ldx, const vita_linear_args& a, hipStream_t stream);
 int launch_pack_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int cols, hipStream_t s);
 int launch_pack_bf16_t(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int K, int M, hipStream_t s);
 int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st);

@@ -1303,6 +1303,26 @@ def linear_bf16(xb: Tensor, wb: Tensor, b: Optional[Tensor] = None, act: int = L
     return y, yb
 
 
+def linear_bf16_tn(ab: Tensor, bb: Tensor, m: Optional[int] = None, n: Optional[int] = None, *, split: bool = True) -> Tensor:
+    """C (m, n) fp32 = ab^T . bb for row-major bf16 bit tensors ab (R, >= m), bb (R, >= n) (pack_bf16 outputs): the weight
+    gradient dW = dY^T X read from the operands as they lie in memory (vita_linear_bf16_tn).  split: let the reduction over R
+    spread over workgroups (deterministic second pass)."""
+    lib = L.load()
+    if ab.dtype != torch.int16 or bb.dtype != torch.int16 or ab.dim() != 2 or bb.dim() != 2 or ab.shape[0] != bb.shape[0]:
+        raise L.VitaHipError("linear_bf16_tn: operands must be pack_bf16 outputs with the same number of rows")
+    if ab.stride(1) != 1 or bb.stride(1) != 1:
+        raise L.VitaHipError("linear_bf16_tn: operands must have unit column stride")
+    R = ab.shape[0]
+    m = ab.shape[1] if m is None else m
+    n = bb.shape[1] if n is None else n
+    c = torch.empty((m, n), dtype=torch.float32, device=ab.device)
+    ws = workspace(ab.device, lib.vita_splitk_workspace_bytes()) if split else None
+    L.check(lib.vita_linear_bf16_tn(ab.data_ptr(), ab.stride(0), bb.data_ptr(), bb.stride(0), c.data_ptr(), n, m, n, R,
+                                    ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, _stream(ab)),
+            "vita_linear_bf16_tn")
+    return c
+
+
 class Bf16Weights:
     """bf16 copies of the GEMM weights of a policy state dict (re-pack after every optimizer step that changes them)."""
 
