@@ -148,6 +148,11 @@ struct Bf16Stage {
             if (sh[i].src == src) { sh[i] = Bf16Shadow{src, bf, ld, rows, cols}; return; }
         if (nsh < 4) sh[nsh++] = Bf16Shadow{src, bf, ld, rows, cols};
     }
+    bool has_shadow(const float* src, const uint16_t* bf) const {
+        for (int i = 0; i < nsh; ++i)
+            if (sh[i].src == src && sh[i].bf == bf) return true;
+        return false;
+    }
     void shadow_drop(const float* src) {
         for (int i = 0; i < nsh; ++i)
             if (sh[i].src == src) { sh[i] = sh[--nsh]; return; }

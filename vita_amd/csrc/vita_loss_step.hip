@@ -226,8 +226,12 @@ struct FlowTrainWs {
     // evaluations e = 0 (flow matching), 1..K (Euler step e-1)
     float *X, *Hs, *HN, *U, *G, *Y2, *DV, *DH0, *DHNF, *RN;
     float *dhn, *DM;
+    // bf16-operand step at large batch: stacked ROW-MAJOR bf16 copies of HN, G and dU (same (l, e) order as the fp32 buffers,
+    // row strides r8(H) / r8(FF)), written by the kernels that produce the fp32 matrices and read by the next GEMM and, as they
+    // lie, by the weight-gradient GEMM on row-major operands (vita_gemm_bf16_tn.hip).  NULL: the transposed-pack route.
+    uint16_t *HNb, *Gb, *dUb;
 };
-FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B, size_t K, bool train) {
+FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B, size_t K, bool train, bool tn = false) {
     FlowTrainWs f{};
     // time-path rows: the B per-row timesteps of the flow-matching evaluation, B more for Euler step 0 (t = 0; it is evaluated
     // together with the flow-matching rows, see vita_compute_loss_f32), one per later step
@@ -257,6 +261,14 @@ FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B,
         f.dhn = c.take(2 * B * H);
         f.DM = c.take(B * L * 3 * H);
     }
+    if (train && tn) {
+        const size_t H8 = (H + 7) & ~size_t(7), FF8 = (FF + 7) & ~size_t(7);
+        uint16_t* hn = reinterpret_cast<uint16_t*>(c.take((L * E * B * H8 + 1) / 2));
+        uint16_t* g = reinterpret_cast<uint16_t*>(c.take((L * E * B * FF8 + 1) / 2));
+        uint16_t* du = reinterpret_cast<uint16_t*>(c.take((L * E * B * FF8 + 1) / 2));
+        // (when only measuring every pointer is null: the flag travels in the pointers, so mark them)
+        f.HNb = hn; f.Gb = g; f.dUb = du;
+    }
     return f;
 }
 
@@ -277,6 +289,12 @@ struct FlowCtx {
     float* DH0(int e) const { return f.DH0 + (size_t)e * bh(); }
     float* DHNF(int e) const { return f.DHNF + (size_t)e * bh(); }
     float* RN(int e) const { return f.RN + (size_t)e * bh(); }
+    int H8() const { return (w->H + 7) & ~7; }
+    int FF8() const { return (w->FF + 7) & ~7; }
+    bool tn() const { return f.Gb != nullptr; }
+    uint16_t* HNb(int l, int e) const { return f.HNb + ((size_t)l * E + e) * B * H8(); }
+    uint16_t* Gb(int l, int e) const { return f.Gb + ((size_t)l * E + e) * B * FF8(); }
+    uint16_t* dUb(int l, int e) const { return f.dUb + ((size_t)l * E + e) * B * FF8(); }
 };
 
 // simple_flow_net.py:66-71,27-30 for the T rows of f.ts, keeping the pre-activations
@@ -337,22 +355,25 @@ int flow_trunk_fwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
     Bf16Stage& bs = bf16_stage();
     bs.nsh = 0;
     const int H8 = (H + 7) & ~7, FF8 = (FF + 7) & ~7;
-    const bool sh = bs.mode != 0 && bs.arena != nullptr && (size_t)B * (H8 + FF8) <= bs.arena_halves &&
-                    (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops);
-    uint16_t* slot_hn = bs.arena;
-    uint16_t* slot_g = sh ? bs.arena + (size_t)B * H8 : nullptr;
+    const bool tn = c.tn() && bs.mode != 0;      // stacked copies kept for the weight-gradient GEMMs
+    const bool sh = tn || (bs.mode != 0 && bs.arena != nullptr && (size_t)B * (H8 + FF8) <= bs.arena_halves &&
+                           (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops));
     VITA_TRY(gemm_f32(lin(c.X(e), D, w->in_w, D, w->in_b, c.Hs(0, e), H, B, H, D, VITA_ACT_NONE), c.st));
     for (int l = 0; l < L; ++l) {
         const float* gamma = mod + (size_t)l * 3 * H;
         const float* scale = gamma + H;
         const float* shift = gamma + 2 * H;
         if (sh) {
+            uint16_t* slot_hn = tn ? c.HNb(l, e) : bs.arena;
+            uint16_t* slot_g = tn ? c.Gb(l, e) : bs.arena + (size_t)B * H8;
             VITA_TRY(launch_ln_mod(c.Hs(l, e), H, c.HN(l, e), H, B, H, 1e-6f, VITA_PRO_LN_MOD, scale, ld_mod, shift, ld_mod, c.st, slot_hn, H8));
             bs.shadow_add(c.HN(l, e), slot_hn, H8, B, H);
             vita_linear_args a = lin(c.HN(l, e), H, w->fc1_w[l], H, w->fc1_b[l], c.G(l, e), FF, B, FF, H, VITA_ACT_GELU_TANH);
             a.preact = c.U(l, e); a.ld_preact = FF;
             bs.emit_y = c.G(l, e); bs.emit_dst = slot_g; bs.emit_ld = FF8;
             VITA_TRY(gemm_f32(a, c.st));
+            // the weight-gradient GEMM reads the stacked copy whatever route this call took (a split or fp32-routed GEMM emits none)
+            if (tn && !bs.has_shadow(c.G(l, e), slot_g)) VITA_TRY(launch_pack_bf16(c.G(l, e), FF, slot_g, FF8, B, FF, c.st));
             vita_linear_args b = lin(c.G(l, e), FF, w->fc2_w[l], FF, w->fc2_b[l], c.Hs(l + 1, e), H, B, H, FF, VITA_ACT_NONE);
             b.preact = c.Y2(l, e); b.ld_preact = H;
             b.gate = gamma; b.ld_gate = ld_mod; b.resid = c.Hs(l, e); b.ld_resid = H;
@@ -399,8 +420,9 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
     Bf16Stage& bs = bf16_stage();      // as in flow_trunk_fwd: dU's bf16 copy comes out of the GEMM that makes dU
     bs.nsh = 0;
     const int FF8 = (FF + 7) & ~7;
-    const bool sh = bs.mode != 0 && bs.arena != nullptr && (size_t)B * FF8 <= bs.arena_halves &&
-                    (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops);
+    const bool tn = c.tn() && bs.mode != 0;
+    const bool sh = tn || (bs.mode != 0 && bs.arena != nullptr && (size_t)B * FF8 <= bs.arena_halves &&
+                           (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops));
     VITA_TRY(gemm_f32(dgrad(c.DV(e), D, w->out_w, H, c.DHNF(e), H, B, H, D), c.st));
     VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(L, e), H, c.DHNF(e), H, w->norm_w, 0, B, H, 1e-5f, VITA_PRO_LN_AFFINE, c.DH0(e), H, 0,
                                              c.RN(e), nullptr, H, c.st));
@@ -412,8 +434,10 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
         VITA_TRY(vita_gate_bwd_f32(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st));
         vita_linear_args a = dgrad(c.Y2(l, e), H, w->fc2_w[l], FF, c.U(l, e), FF, B, FF, H);   // dU = (dY2 . W2) * gelu_tanh'(U)
         a.act = VITA_ACT_GELU_TANH; a.act_grad_z = c.U(l, e); a.ld_act_grad_z = FF;
-        if (sh) { bs.emit_y = c.U(l, e); bs.emit_dst = bs.arena; bs.emit_ld = FF8; }
+        uint16_t* slot_du = tn ? c.dUb(l, e) : bs.arena;
+        if (sh) { bs.emit_y = c.U(l, e); bs.emit_dst = slot_du; bs.emit_ld = FF8; }
         VITA_TRY(gemm_f32(a, c.st));
+        if (tn && !bs.has_shadow(c.U(l, e), slot_du)) VITA_TRY(launch_pack_bf16(c.U(l, e), FF, slot_du, FF8, B, FF, c.st));
         VITA_TRY(gemm_f32(dgrad(c.U(l, e), FF, w->fc1_w[l], H, c.f.dhn, H, B, H, FF), c.st));
         bs.nsh = 0;
         VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(l, e), H, c.f.dhn, H, scale, ld_mod, B, H, 1e-6f, VITA_PRO_LN_MOD, c.DH0(e), H, 1,
@@ -459,7 +483,20 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
         VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
         VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
     }
+    Bf16Stage& bs = bf16_stage();
+    const int H8 = c.H8(), FF8 = c.FF8();
+    const bool tn = c.tn() && bs.mode != 0 && bs.ptr != nullptr && (size_t)R * H8 * 2 <= bs.bytes;
     for (int l = 0; l < L && (parts & kWgLayers); ++l) {
+        if (tn) {
+            // row-major bf16 operands as the forward / backward kernels left them (dY2: one row pack into the staging buffer):
+            // no transposed copies of the R-row operands
+            uint16_t* y2b = static_cast<uint16_t*>(bs.ptr);
+            VITA_TRY(launch_pack_bf16(c.Y2(l, 0), H, y2b, H8, R, H, c.st));
+            VITA_TRY(gemm_bf16_wgrad_tn(y2b, H8, c.Gb(l, 0), FF8, wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
+            VITA_TRY(gemm_bf16_wgrad_tn(c.dUb(l, 0), FF8, c.HNb(l, 0), H8, wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
+            if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
+            continue;
+        }
         VITA_TRY(gemm_f32(wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
         VITA_TRY(gemm_f32(wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
         if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
@@ -635,6 +672,12 @@ size_t bf16_stage_bytes(const vita_policy_weights& w, size_t B, size_t K) {
     return ((by_rows > by_w ? by_rows : by_w) + 1023) & ~size_t(255);
 }
 
+// lab switch: VITA_WGRAD_TN=0 keeps the transposed-pack route of the weight-gradient GEMMs (A/B measurements)
+bool wgrad_tn_enabled() {
+    static const bool on = [] { const char* e = getenv("VITA_WGRAD_TN"); return e == nullptr || e[0] != '0'; }();
+    return on;
+}
+
 StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config& cfg, size_t B, bool train) {
     Carver c(ws);
     StepWs s{};
@@ -677,11 +720,12 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
     }
     s.wt = (train && B >= (size_t)kWtMinRows) ? c.take(wt_floats(&w.flow, nullptr, w.dec, w.enc)) : nullptr;
     s.wb = (cfg.gemm_bf16 && B >= (size_t)kWtMinRows) ? reinterpret_cast<uint16_t*>(c.take((wb_halves(&w.flow, w.dec, w.enc) + 1) / 2)) : nullptr;
-    if (cfg.gemm_bf16 && B >= (size_t)kWtMinRows) {      // (the same predicate as wb: when only measuring, every pointer is null)
+    const bool tn = train && cfg.gemm_bf16 && B >= (size_t)kWtMinRows && w.flow.H % 8 == 0 && w.flow.FF % 8 == 0 && wgrad_tn_enabled();
+    if (cfg.gemm_bf16 && B >= (size_t)kWtMinRows && !tn) {      // (the same predicate as wb: when only measuring, every pointer is null)
         s.arena_halves = 2 * B * ((((size_t)w.flow.H + 7) & ~size_t(7)) + (((size_t)w.flow.FF + 7) & ~size_t(7)));
         s.arena = reinterpret_cast<uint16_t*>(c.take((s.arena_halves + 1) / 2));
     }
-    s.flow = carve_flow_train(c, w.flow, B, K, train);
+    s.flow = carve_flow_train(c, w.flow, B, K, train, tn);
     if (!cfg.external_decoder) s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
     if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
     else if (w.enc.kind == VITA_ENC_CNN) s.cnn = carve_cnn(c, w.enc, B, train);
