@@ -58,8 +58,12 @@ __global__ __launch_bounds__(TNT, 2) void gemm_bf16_tn_kernel(GemmParamsTN p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
+    // workgroup ids go round-robin over the 8 XCDs: give each XCD a CONTIGUOUS range of (split, tile) ids, so that its L2
+    // fetches one split's rows (with 8 splits: 1/8 of both operands) instead of all of them
     const int ntile = p.tiles_m * p.tiles_n;
-    const int split = blockIdx.x / ntile, t = blockIdx.x % ntile;
+    const int total = gridDim.x;
+    const int bid = (total % 8 == 0) ? (blockIdx.x % 8) * (total / 8) + blockIdx.x / 8 : blockIdx.x;
+    const int split = bid / ntile, t = bid % ntile;
     const int m0 = (t / p.tiles_n) * TBM, n0 = (t % p.tiles_n) * TBN;
     const int rbase = split * p.sk_r;
     const int R = p.sk_splits > 1 ? min(p.R, rbase + p.sk_r) : p.R;

@@ -512,7 +512,9 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
     st.shadow_drop(a.Y);
     uint16_t* emit_dst = (st.emit_y != nullptr && st.emit_y == a.Y) ? st.emit_dst : nullptr;
     const int64_t emit_ld = st.emit_ld;
+    const bool emit_only = st.emit_only;
     st.emit_y = nullptr;
+    st.emit_only = false;
     if (st.mode == 0 || st.ptr == nullptr || a.pro != VITA_PRO_NONE || a.M <= 0 || a.N <= 0 || a.K <= 0) return VITA_OK;
     if (st.mode == 1 && 2.0 * (double)a.M * (double)a.N * (double)a.K < kBf16MinFlops) return VITA_OK;
     const int Kp = (a.K + 7) & ~7;
@@ -553,6 +555,7 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
     u.K = Kp / 2;                               // the kernel counts k in 4-byte units (bf16 pairs)
     const SplitK sk = plan_splitk(u);
     const bool emit = emit_dst != nullptr && sk.splits <= 1 && emit_ld >= a.N && emit_ld % 8 == 0;   // a split GEMM's epilogue is the reduce pass
+    if (emit && emit_only) { b.Y = nullptr; b.ldy = 0; }     // the caller reads only the bf16 copy
     VITA_TRY_RC(gemm_bf16_dma(b, emit ? emit_dst : nullptr, emit ? emit_ld : 0, stream, sk.splits > 1 ? &sk : nullptr));
     if (sk.splits > 1) VITA_TRY_RC(launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream));
     if (emit) st.shadow_add(a.Y, emit_dst, emit_ld, a.M, a.N);

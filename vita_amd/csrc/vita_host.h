@@ -67,6 +67,9 @@ int gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
 int gemm_bf16_wgrad_tn(const uint16_t* dYb, int64_t ld_dy, const uint16_t* Xb, int64_t ldx, const vita_linear_args& a, hipStream_t stream);
 int launch_pack_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int cols, hipStream_t s);
 int launch_pack_bf16_t(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int K, int M, hipStream_t s);
+// vita_gate_bwd_f32 with an optional bf16 copy of dz (row stride ld_bf16) for the bf16-operand step
+int launch_gate_bwd(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz, float* dgate_rows,
+                    int64_t ld_dgate, int M, int N, hipStream_t s, uint16_t* dz_bf16, int64_t ld_bf16);
 int launch_set_scalars(float* out, const float* host_vals, int n, hipStream_t st);
 int launch_weighted_sum(const float* vals, const float* host_w, int n, float* out, hipStream_t st);
 
@@ -142,6 +145,7 @@ struct Bf16Stage {
     void* ptr = nullptr; size_t bytes = 0; int mode = 0; Bf16WEntry wc[80]; int nwc = 0;
     Bf16Shadow sh[4]; int nsh = 0;
     const float* emit_y = nullptr; uint16_t* emit_dst = nullptr; int64_t emit_ld = 0;
+    bool emit_only = false;     // with emit_y: when the bf16 copy IS written, skip the fp32 output (nobody reads it)
     uint16_t* arena = nullptr; size_t arena_halves = 0;      // shadow slots of the running step (vita_loss_step.hip)
     void shadow_add(const float* src, const uint16_t* bf, int64_t ld, int rows, int cols) {
         for (int i = 0; i < nsh; ++i)
@@ -164,7 +168,7 @@ inline Bf16Stage& bf16_stage() {
 }
 struct Bf16Scope {
     Bf16Stage saved;
-    Bf16Scope(void* p, size_t n, int mode) : saved(bf16_stage()) { bf16_stage().ptr = p; bf16_stage().bytes = n; bf16_stage().mode = mode; bf16_stage().nwc = 0; bf16_stage().nsh = 0; bf16_stage().emit_y = nullptr; bf16_stage().arena = nullptr; bf16_stage().arena_halves = 0; }
+    Bf16Scope(void* p, size_t n, int mode) : saved(bf16_stage()) { bf16_stage().ptr = p; bf16_stage().bytes = n; bf16_stage().mode = mode; bf16_stage().nwc = 0; bf16_stage().nsh = 0; bf16_stage().emit_y = nullptr; bf16_stage().emit_only = false; bf16_stage().arena = nullptr; bf16_stage().arena_halves = 0; }
     ~Bf16Scope() { bf16_stage() = saved; }
 };
 // Transposed copies of weights for the input-gradient GEMMs of a large-batch training step: dX = dY . W with W (out, in)

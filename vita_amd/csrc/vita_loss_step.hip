@@ -226,10 +226,10 @@ struct FlowTrainWs {
     // evaluations e = 0 (flow matching), 1..K (Euler step e-1)
     float *X, *Hs, *HN, *U, *G, *Y2, *DV, *DH0, *DHNF, *RN;
     float *dhn, *DM;
-    // bf16-operand step at large batch: stacked ROW-MAJOR bf16 copies of HN, G and dU (same (l, e) order as the fp32 buffers,
+    // bf16-operand step at large batch: stacked ROW-MAJOR bf16 copies of HN, G, dU and dY2 (same (l, e) order as the fp32 buffers,
     // row strides r8(H) / r8(FF)), written by the kernels that produce the fp32 matrices and read by the next GEMM and, as they
     // lie, by the weight-gradient GEMM on row-major operands (vita_gemm_bf16_tn.hip).  NULL: the transposed-pack route.
-    uint16_t *HNb, *Gb, *dUb;
+    uint16_t *HNb, *Gb, *dUb, *Y2b;
 };
 FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B, size_t K, bool train, bool tn = false) {
     FlowTrainWs f{};
@@ -267,7 +267,8 @@ FlowTrainWs carve_flow_train(Carver& c, const vita_flownet_weights& w, size_t B,
         uint16_t* g = reinterpret_cast<uint16_t*>(c.take((L * E * B * FF8 + 1) / 2));
         uint16_t* du = reinterpret_cast<uint16_t*>(c.take((L * E * B * FF8 + 1) / 2));
         // (when only measuring every pointer is null: the flag travels in the pointers, so mark them)
-        f.HNb = hn; f.Gb = g; f.dUb = du;
+        uint16_t* y2 = reinterpret_cast<uint16_t*>(c.take((L * E * B * H8 + 1) / 2));
+        f.HNb = hn; f.Gb = g; f.dUb = du; f.Y2b = y2;
     }
     return f;
 }
@@ -294,6 +295,7 @@ struct FlowCtx {
     bool tn() const { return f.Gb != nullptr; }
     uint16_t* HNb(int l, int e) const { return f.HNb + ((size_t)l * E + e) * B * H8(); }
     uint16_t* Gb(int l, int e) const { return f.Gb + ((size_t)l * E + e) * B * FF8(); }
+    uint16_t* Y2b(int l, int e) const { return f.Y2b + ((size_t)l * E + e) * B * H8(); }
     uint16_t* dUb(int l, int e) const { return f.dUb + ((size_t)l * E + e) * B * FF8(); }
 };
 
@@ -371,6 +373,7 @@ int flow_trunk_fwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
             vita_linear_args a = lin(c.HN(l, e), H, w->fc1_w[l], H, w->fc1_b[l], c.G(l, e), FF, B, FF, H, VITA_ACT_GELU_TANH);
             a.preact = c.U(l, e); a.ld_preact = FF;
             bs.emit_y = c.G(l, e); bs.emit_dst = slot_g; bs.emit_ld = FF8;
+            bs.emit_only = tn;      // with the stacked copies nothing reads G in fp32: fc2 and the weight gradient take the bf16 one
             VITA_TRY(gemm_f32(a, c.st));
             // the weight-gradient GEMM reads the stacked copy whatever route this call took (a split or fp32-routed GEMM emits none)
             if (tn && !bs.has_shadow(c.G(l, e), slot_g)) VITA_TRY(launch_pack_bf16(c.G(l, e), FF, slot_g, FF8, B, FF, c.st));
@@ -431,7 +434,12 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
         const float* scale = gamma + H;
         float* dmr = dm_rows + (size_t)l * 3 * H;
         // x_{l+1} = x_l + y2 * gamma
-        VITA_TRY(vita_gate_bwd_f32(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st));
+        if (tn) {      // dY2's bf16 copy comes out of the kernel that makes dY2: the next GEMM's A operand, and the weight gradient's
+            VITA_TRY(launch_gate_bwd(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st, c.Y2b(l, e), c.H8()));
+            bs.shadow_add(c.Y2(l, e), c.Y2b(l, e), c.H8(), B, H);
+        } else {
+            VITA_TRY(vita_gate_bwd_f32(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st));
+        }
         vita_linear_args a = dgrad(c.Y2(l, e), H, w->fc2_w[l], FF, c.U(l, e), FF, B, FF, H);   // dU = (dY2 . W2) * gelu_tanh'(U)
         a.act = VITA_ACT_GELU_TANH; a.act_grad_z = c.U(l, e); a.ld_act_grad_z = FF;
         uint16_t* slot_du = tn ? c.dUb(l, e) : bs.arena;
@@ -485,14 +493,11 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
     }
     Bf16Stage& bs = bf16_stage();
     const int H8 = c.H8(), FF8 = c.FF8();
-    const bool tn = c.tn() && bs.mode != 0 && bs.ptr != nullptr && (size_t)R * H8 * 2 <= bs.bytes;
+    const bool tn = c.tn() && bs.mode != 0;
     for (int l = 0; l < L && (parts & kWgLayers); ++l) {
         if (tn) {
-            // row-major bf16 operands as the forward / backward kernels left them (dY2: one row pack into the staging buffer):
-            // no transposed copies of the R-row operands
-            uint16_t* y2b = static_cast<uint16_t*>(bs.ptr);
-            VITA_TRY(launch_pack_bf16(c.Y2(l, 0), H, y2b, H8, R, H, c.st));
-            VITA_TRY(gemm_bf16_wgrad_tn(y2b, H8, c.Gb(l, 0), FF8, wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
+            // row-major bf16 operands as the forward / backward kernels left them: no packs, no transposed copies
+            VITA_TRY(gemm_bf16_wgrad_tn(c.Y2b(l, 0), H8, c.Gb(l, 0), FF8, wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
             VITA_TRY(gemm_bf16_wgrad_tn(c.dUb(l, 0), FF8, c.HNb(l, 0), H8, wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
             if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
             continue;

@@ -26,8 +26,10 @@ __global__ __launch_bounds__(TT) void act_fwd_kernel(const float* __restrict__ z
 // ---- gate backward: y = r + z*g ------------------------------------------------------------------
 // dz = dy*g ; dg_rows = dy*z (optional).  g: vector (ld_g = 0), matrix (ld_g >= N) or scalar (g == NULL).
 // dy, z, dz are contiguous (M,N); z and dz may be the same buffer (each element is read, then written, by one thread).
+// dzb: optional bf16 copy of dz, row stride ld_b (the bf16-operand step: dz is the next GEMM's A operand).
 __global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ dy, const float* z, const float* __restrict__ g,
-                                                     int64_t ld_g, float gs, float* dz, float* __restrict__ dg, int64_t ld_dg, int M, int N) {
+                                                     int64_t ld_g, float gs, float* dz, float* __restrict__ dg, int64_t ld_dg, int M, int N,
+                                                     uint16_t* __restrict__ dzb, int64_t ld_b) {
     const int64_t n = (int64_t)M * N, stride = (int64_t)gridDim.x * TT;
     for (int64_t i = (int64_t)blockIdx.x * TT + threadIdx.x; i < n; i += stride) {
         const int r = (int)(i / N), c = (int)(i - (int64_t)r * N);
@@ -35,6 +37,7 @@ __global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ 
         const float gv = g ? g[(int64_t)r * ld_g + c] : gs;
         if (dg) dg[(int64_t)r * ld_dg + c] = d * z[i];
         if (dz) dz[i] = d * gv;
+        if (dzb) dzb[(int64_t)r * ld_b + c] = f32_to_bf16(d * gv);
     }
 }
 
@@ -545,15 +548,24 @@ int vita_act_bwd_f32(const float* z, const float* dy, float* dz, int64_t n, int3
 }
 int vita_gate_bwd_f32(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz, float* dgate_rows,
                       int64_t ld_dgate, int32_t M, int32_t N, vita_stream_t s) {
+    return vita::launch_gate_bwd(dy, z, gate, ld_gate, gate_scalar, dz, dgate_rows, ld_dgate, M, N, (hipStream_t)s, nullptr, 0);
+}
+}  // extern "C"
+namespace vita {
+int launch_gate_bwd(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz, float* dgate_rows,
+                    int64_t ld_dgate, int M, int N, hipStream_t s, uint16_t* dz_bf16, int64_t ld_bf16) {
     VITA_REQUIRE(dy && M >= 0 && N > 0, "vita_gate_bwd_f32: bad arguments");
+    VITA_REQUIRE(dz_bf16 == nullptr || (ld_bf16 >= N && (N % 8 == 0 || ld_bf16 == N)), "vita_gate_bwd_f32: bad bf16 output stride");
     VITA_REQUIRE(dgate_rows == nullptr || (z != nullptr && ld_dgate >= N), "vita_gate_bwd_f32: dgate needs z and ld_dgate >= N");
     VITA_REQUIRE(gate == nullptr || ld_gate == 0 || ld_gate >= N, "vita_gate_bwd_f32: ld_gate must be 0 or >= N");
     VITA_REQUIRE(dz == nullptr || dz != dy, "vita_gate_bwd_f32: dz must not alias dy");
-    if (M == 0 || (!dz && !dgate_rows)) return VITA_OK;
+    if (M == 0 || (!dz && !dgate_rows && !dz_bf16)) return VITA_OK;
     hipLaunchKernelGGL(gate_bwd_kernel, dim3(tgrid((int64_t)M * N)), dim3(TT), 0, (hipStream_t)s, dy, z, gate, ld_gate, gate_scalar, dz,
-                       dgate_rows, ld_dgate, M, N);
+                       dgate_rows, ld_dgate, M, N, dz_bf16, ld_bf16);
     LAUNCH_OK();
 }
+}  // namespace vita
+extern "C" {
 int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul, int32_t M,
                                     int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, int32_t dx_accumulate, float* dmul_rows,
                                     float* dadd_rows, int64_t ld_drows, vita_stream_t s) {
