@@ -71,6 +71,27 @@ def test_bf16_all_gemms_small_unaligned_dims(ops, dev, enc):
     assert torch.equal(l16, l16b) and all(torch.equal(g16[k], g16b[k]) for k in g16), "bf16 step not deterministic"
 
 
+@pytest.mark.parametrize("enc", ["cnn", "simple"])
+def test_bf16_row_major_weight_gradients_b1024(ops, dev, enc):
+    """B = 1024, mode 2: from 1024 rows on the step keeps row-major bf16 copies of the flow net's HN / G / dU / dY2 and of the
+    decoder's (and the simple encoder's) A / G / dP / dA, written by the kernels that produce them, and the weight-gradient
+    GEMMs read them as they lie (transposed LDS reads, vita_gemm_bf16_tn.hip).  Same tolerances as every bf16 step; small dims
+    (multiples of 8: the row-major kernel's requirement) keep it quick; the ragged ones (O = 41, A = 7) stay on the packed route."""
+    A, T, B = 7, 16, 1024
+    sd = O.make_state_dict(41, A, latent_dim=64, hidden_dim=64, num_layers=3, pred_horizon=T, ae_hidden=48, ae_layers=4 if enc == "cnn" else 2,
+                           time_embed_dim=32, seed=5, encoder_type=enc)
+    g = torch.Generator().manual_seed(16)
+    obs, actions, t = torch.randn(B, 41, generator=g), torch.randn(B, T, A, generator=g), torch.rand(B, generator=g)
+    l32, g32, d32 = step(ops, dev, sd, obs, actions, t)
+    l16, g16, d16 = step(ops, dev, sd, obs, actions, t, gemm_bf16=2)
+    assert not torch.equal(l32, l16)
+    compare(l32, g32, l16, g16, f"B=1024 {enc}")
+    cos = (d16.flatten() @ d32.flatten() / (d16.norm() * d32.norm())).item()
+    assert cos >= 0.99
+    l16b, g16b, _ = step(ops, dev, sd, obs, actions, t, gemm_bf16=2)
+    assert torch.equal(l16, l16b) and all(torch.equal(g16[k], g16b[k]) for k in g16), "bf16 step not deterministic"
+
+
 def test_bf16_staging_is_exact_on_bf16_representable_operands(ops, dev):
     """With weights, inputs and every intermediate representable in bf16 the two paths must agree to fp32 summation
     order: a one-layer linear chain (obs_encoder only matters) cannot be isolated through the C ABI, so this checks the

@@ -43,7 +43,27 @@ struct StackWs {
     float *out = nullptr;  // (M, OUT)
     float *dOut = nullptr; // (M, OUT)
     float *dA[VITA_MAX_LAYERS + 1] = {};  // (M, TR) gradient of trunk activation i, i = 0..NL: each kept until its wgrad has run
+    // bf16-operand step at large batch (carve_stack's `tn`): row-major bf16 copies of A, G, dP and dA, written by the GEMM that
+    // produces each matrix; the next GEMM reads them as its A operand and the weight-gradient GEMMs read them as they lie
+    // (vita_gemm_bf16_tn.hip).  Row strides r8(TR) / r8(FF).  NULL: operands are packed per call.
+    uint16_t *Ab = nullptr, *Gb = nullptr, *dPb = nullptr;
+    uint16_t *dAb[VITA_MAX_LAYERS + 1] = {};
+    bool tn() const { return Ab != nullptr; }
 };
+inline int r8i(int v) { return (v + 7) & ~7; }
+// after a GEMM that was asked to emit the bf16 copy `dst` of its output y: make sure the copy exists (a split or fp32-routed
+// GEMM writes none) and is registered as y's shadow for the next GEMM
+int emit_or_pack(const float* y, int64_t ldy, uint16_t* dst, int64_t ld, int M, int N, hipStream_t st) {
+    Bf16Stage& bs = bf16_stage();
+    if (bs.has_shadow(y, dst)) return VITA_OK;
+    VITA_TRY(launch_pack_bf16(y, ldy, dst, ld, M, N, st));
+    bs.shadow_add(y, dst, ld, M, N);
+    return VITA_OK;
+}
+inline void emit_request(const float* y, uint16_t* dst, int64_t ld, bool only = false) {
+    Bf16Stage& bs = bf16_stage();
+    bs.emit_y = y; bs.emit_dst = dst; bs.emit_ld = ld; bs.emit_only = only;
+}
 Stack stack_of(const vita_decoder_weights& w) {
     Stack s;
     s.IN = w.D; s.TR = w.HD; s.FF = w.HD; s.NL = w.NL; s.OUT = w.OUT;
@@ -58,7 +78,12 @@ Stack stack_of_simple_encoder(const vita_encoder_weights& w) {
     for (int i = 0; i < w.NL; ++i) { s.fc1_w[i] = w.w1[i]; s.fc1_b[i] = w.b1[i]; s.fc2_w[i] = w.w2[i]; s.fc2_b[i] = w.b2[i]; }
     return s;
 }
-StackWs carve_stack(Carver& c, const Stack& s, size_t M, bool train) {
+// whether the stack's GEMMs over M rows all take the bf16 route and its dims suit the row-major weight-gradient kernel
+bool stack_tn_ok(const Stack& s, size_t M, int mode) {
+    return mode != 0 && M >= (size_t)kWtMinRows && s.TR % 8 == 0 && s.FF % 8 == 0 && s.NL > 0 &&
+           (mode == 2 || 2.0 * (double)M * s.TR * (s.TR < s.FF ? s.TR : s.FF) >= kBf16MinFlops);
+}
+StackWs carve_stack(Carver& c, const Stack& s, size_t M, bool train, bool tn = false) {
     StackWs w;
     w.A = c.take((size_t)(s.NL + 1) * M * s.TR);
     w.P = c.take((size_t)s.NL * M * s.FF);
@@ -68,20 +93,38 @@ StackWs carve_stack(Carver& c, const Stack& s, size_t M, bool train) {
         if (s.OUT) w.dOut = c.take(M * s.OUT);
         for (int i = 0; i <= s.NL; ++i) w.dA[i] = c.take(M * s.TR);
     }
+    if (train && tn) {
+        auto halves = [&](size_t n) { return reinterpret_cast<uint16_t*>(c.take((n + 1) / 2)); };
+        const size_t tr8 = r8i(s.TR), ff8 = r8i(s.FF);
+        w.Ab = halves((size_t)(s.NL + 1) * M * tr8);
+        w.Gb = halves((size_t)s.NL * M * ff8);
+        w.dPb = halves((size_t)s.NL * M * ff8);
+        for (int i = 0; i <= s.NL; ++i) w.dAb[i] = halves(M * tr8);
+    }
     return w;
 }
 // last_trunk: when non-null the final trunk activation A[NL] is written there instead (contiguous (M, TR))
 int stack_fwd(const Stack& s, const StackWs& w, const float* x, int64_t ldx, int M, float* last_trunk, hipStream_t st) {
     const size_t tr = (size_t)M * s.TR, ff = (size_t)M * s.FF;
     auto trunk = [&](int i) { return (i == s.NL && last_trunk) ? last_trunk : w.A + (size_t)i * tr; };
+    const bool tn = w.tn() && bf16_stage().mode != 0;
+    const int tr8 = r8i(s.TR), ff8 = r8i(s.FF);
+    auto Ab = [&](int i) { return w.Ab + (size_t)i * M * tr8; };
+    auto Gb = [&](int i) { return w.Gb + (size_t)i * M * ff8; };
+    if (tn) { bf16_stage().nsh = 0; emit_request(trunk(0), Ab(0), tr8); }
     VITA_TRY(gemm_f32(lin(x, ldx, s.in_w, s.IN, s.in_b, trunk(0), s.TR, M, s.TR, s.IN, VITA_ACT_NONE), st));
+    if (tn) VITA_TRY(emit_or_pack(trunk(0), s.TR, Ab(0), tr8, M, s.TR, st));
     for (int i = 0; i < s.NL; ++i) {
         vita_linear_args a = lin(trunk(i), s.TR, s.fc1_w[i], s.TR, s.fc1_b[i], w.G + i * ff, s.FF, M, s.FF, s.TR, VITA_ACT_GELU_ERF);
         a.preact = w.P + i * ff; a.ld_preact = s.FF;
+        if (tn) emit_request(w.G + i * ff, Gb(i), ff8, true);      // (nothing reads G in fp32 then: fc2 and the weight gradient take the copy)
         VITA_TRY(gemm_f32(a, st));
+        if (tn) { VITA_TRY(emit_or_pack(w.G + i * ff, s.FF, Gb(i), ff8, M, s.FF, st)); emit_request(trunk(i + 1), Ab(i + 1), tr8); }
         VITA_TRY(gemm_f32(lin(w.G + i * ff, s.FF, s.fc2_w[i], s.FF, s.fc2_b[i], trunk(i + 1), s.TR, M, s.TR, s.FF, VITA_ACT_NONE), st));
+        if (tn) VITA_TRY(emit_or_pack(trunk(i + 1), s.TR, Ab(i + 1), tr8, M, s.TR, st));
     }
     if (s.OUT) VITA_TRY(gemm_f32(lin(trunk(s.NL), s.TR, s.out_w, s.TR, s.out_b, w.out, s.OUT, M, s.OUT, s.TR, VITA_ACT_NONE), st));
+    if (tn) bf16_stage().nsh = 0;
     return VITA_OK;
 }
 // Backward of the stack in two parts so that a caller may run them on different streams: the input-gradient chain
@@ -93,19 +136,31 @@ int stack_chain_bwd(const Stack& s, const StackWs& w, int M, const float* d_top,
     const size_t ff = (size_t)M * s.FF;
     const float* dA = d_top;
     int64_t ld_dA = ld_top;
+    const bool tn = w.tn() && bf16_stage().mode != 0;
+    const int tr8 = r8i(s.TR), ff8 = r8i(s.FF);
+    if (tn) bf16_stage().nsh = 0;
     if (s.OUT) {
+        if (tn) emit_request(w.dA[s.NL], w.dAb[s.NL], tr8);
         VITA_TRY(gemm_f32(dgrad(d_top, ld_top, s.out_w, s.TR, w.dA[s.NL], s.TR, M, s.TR, s.OUT), st));
         dA = w.dA[s.NL]; ld_dA = s.TR;
     }
+    // (without an output projection the top gradient comes from the caller in fp32: one row pack, shared by the GEMM below and
+    // the weight gradient)
+    if (tn) VITA_TRY(emit_or_pack(dA, ld_dA, w.dAb[s.NL], tr8, M, s.TR, st));
     for (int i = s.NL - 1; i >= 0; --i) {
         float* P = w.P + i * ff;
         vita_linear_args a = dgrad(dA, ld_dA, s.fc2_w[i], s.FF, P, s.FF, M, s.FF, s.TR);   // dP = (dA . W2) * gelu'(P), in place
         a.act = VITA_ACT_GELU_ERF; a.act_grad_z = P; a.ld_act_grad_z = s.FF;
+        uint16_t* dPb = tn ? w.dPb + (size_t)i * M * ff8 : nullptr;
+        if (tn) emit_request(P, dPb, ff8);
         VITA_TRY(gemm_f32(a, st));
+        if (tn) { VITA_TRY(emit_or_pack(P, s.FF, dPb, ff8, M, s.FF, st)); emit_request(w.dA[i], w.dAb[i], tr8); }
         VITA_TRY(gemm_f32(dgrad(P, s.FF, s.fc1_w[i], s.TR, w.dA[i], s.TR, M, s.TR, s.FF), st));
+        if (tn) VITA_TRY(emit_or_pack(w.dA[i], s.TR, w.dAb[i], tr8, M, s.TR, st));
         dA = w.dA[i]; ld_dA = s.TR;
     }
     if (dx) VITA_TRY(gemm_f32(dgrad(dA, ld_dA, s.in_w, s.IN, dx, ld_dx, M, s.IN, s.TR), st));
+    if (tn) bf16_stage().nsh = 0;
     return VITA_OK;
 }
 inline float* mut(const float* p) { return const_cast<float*>(p); }
@@ -121,11 +176,20 @@ int stack_wgrads(const Stack& s, const Stack& g, const StackWs& w, const float* 
         VITA_TRY(gemm_f32(wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT), st));
         VITA_TRY(cb.add(d_top, ld_top, M, s.OUT, mut(g.out_b)));
     }
+    const bool tn = w.tn() && bf16_stage().mode != 0;
+    const int tr8 = r8i(s.TR), ff8 = r8i(s.FF);
     for (int i = s.NL - 1; i >= 0; --i) {
         const float* P = w.P + i * ff;
-        VITA_TRY(gemm_f32(wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
+        if (tn) {   // the operands' bf16 copies as the forward / backward GEMMs left them
+            VITA_TRY(gemm_bf16_wgrad_tn(w.dAb[i + 1], tr8, w.Gb + (size_t)i * M * ff8, ff8,
+                                        wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
+            VITA_TRY(gemm_bf16_wgrad_tn(w.dPb + (size_t)i * M * ff8, ff8, w.Ab + (size_t)i * M * tr8, tr8,
+                                        wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
+        } else {
+            VITA_TRY(gemm_f32(wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
+            VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
+        }
         VITA_TRY(cb.add(dA(i + 1), ld_dA(i + 1), M, s.TR, mut(g.fc2_b[i])));
-        VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
         VITA_TRY(cb.add(P, s.FF, M, s.FF, mut(g.fc1_b[i])));
     }
     VITA_TRY(gemm_f32(wgrad(dA(0), ld_dA(0), x, ldx, mut(g.in_w), s.IN, M, s.IN, s.TR), st));
@@ -731,8 +795,11 @@ StepWs carve_step(void* ws, const vita_policy_weights& w, const vita_loss_config
         s.arena = reinterpret_cast<uint16_t*>(c.take((s.arena_halves + 1) / 2));
     }
     s.flow = carve_flow_train(c, w.flow, B, K, train, tn);
-    if (!cfg.external_decoder) s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train);
-    if (w.enc.kind == VITA_ENC_SIMPLE) s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train);
+    if (!cfg.external_decoder)
+        s.dec = carve_stack(c, stack_of(w.dec), 2 * B, train, train && wgrad_tn_enabled() && stack_tn_ok(stack_of(w.dec), 2 * B, cfg.gemm_bf16));
+    if (w.enc.kind == VITA_ENC_SIMPLE)
+        s.senc = carve_stack(c, stack_of_simple_encoder(w.enc), B * w.enc.T, train,
+                             train && wgrad_tn_enabled() && stack_tn_ok(stack_of_simple_encoder(w.enc), B * w.enc.T, cfg.gemm_bf16));
     else if (w.enc.kind == VITA_ENC_CNN) s.cnn = carve_cnn(c, w.enc, B, train);
     s.bytes = c.off;
     return s;
