@@ -3,7 +3,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 CSRC  := vita_amd/csrc
-SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_gemm_f32_dma.hip $(CSRC)/vita_gemm_f32_t.hip $(CSRC)/vita_gemm_f32_small.hip $(CSRC)/vita_gemm_bf16_tn.hip $(CSRC)/vita_elementwise.hip $(CSRC)/vita_train.hip $(CSRC)/vita_loss_step.hip $(CSRC)/vita_api_bf16.hip $(CSRC)/vita_contrastive.hip $(CSRC)/vita_meanflow.hip $(CSRC)/vita_ode_persistent.hip $(CSRC)/vita_ode_resident.hip $(CSRC)/vita_data.hip $(CSRC)/vita_observer.hip
+SRCS  := $(CSRC)/vita_api.hip $(CSRC)/vita_gemm_f32.hip $(CSRC)/vita_gemm_f32_dma.hip $(CSRC)/vita_gemm_f32_t.hip $(CSRC)/vita_gemm_f32_small.hip $(CSRC)/vita_gemm_bf16_tn.hip $(CSRC)/vita_gemm_f32_tn.hip $(CSRC)/vita_elementwise.hip $(CSRC)/vita_train.hip $(CSRC)/vita_loss_step.hip $(CSRC)/vita_api_bf16.hip $(CSRC)/vita_contrastive.hip $(CSRC)/vita_meanflow.hip $(CSRC)/vita_ode_persistent.hip $(CSRC)/vita_ode_resident.hip $(CSRC)/vita_data.hip $(CSRC)/vita_observer.hip
 HDRS  := $(CSRC)/vita_common.h $(CSRC)/vita_host.h $(CSRC)/vita_gemm_epilogue.h $(CSRC)/vita_gemm_dma_tile.h $(CSRC)/vita_ode_sync.h $(CSRC)/vita_splitk_fused.h include/vita_hip.h
 OBJS  := $(SRCS:.hip=.o)
 LIB   := vita_amd/libvita_hip.so

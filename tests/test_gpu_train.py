@@ -55,7 +55,10 @@ def close(a, b, tol, what=""):
 # transposed-operand GEMM: dgrad / wgrad / fused activation derivative
 # ----------------------------------------------------------------------------------------
 @pytest.mark.parametrize("M,IN,OUT", [(1, 1, 1), (5, 32, 32), (128, 512, 2048), (130, 533, 512), (37, 105, 32), (4096, 512, 512),
-                                      (896, 2048, 512), (64, 336, 512)])
+                                      (896, 2048, 512), (64, 336, 512),
+                                      # from 2048 stacked rows the weight gradient takes the row-major LDS-DMA kernel
+                                      # (vita_gemm_f32_tn.hip): ragged R, ragged M / N (multiples of 4), the step's own shapes
+                                      (2048, 2048, 512), (5000, 336, 512), (3001, 132, 68), (28672, 512, 2048), (2050, 533, 512)])
 def test_dgrad_wgrad(ops, dev, M, IN, OUT):
     g = torch.Generator().manual_seed(M + IN + OUT)
     x = torch.randn(M, IN, generator=g)

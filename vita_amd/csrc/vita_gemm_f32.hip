@@ -473,6 +473,13 @@ static EpiParams epi_of(const vita_linear_args& a) {
     return e;
 }
 
+// rows of reduction from which a weight-gradient GEMM (both operands reduced over their row index) takes the row-major LDS-DMA
+// kernel instead of the register-staged one; VITA_F32_TN_MIN_ROWS overrides (lab / A-B measurements)
+static int tn_min_rows() {
+    static const int v = [] { const char* e = getenv("VITA_F32_TN_MIN_ROWS"); return e != nullptr ? atoi(e) : 2048; }();
+    return v;
+}
+
 // dW = dY^T X from ROW-MAJOR bf16 copies of dY (R, M) and X (R, N) (vita_gemm_bf16_tn.hip): the reduction over the R stacked rows
 // is split over workgroups until ~2 workgroups per CU are in flight, then summed by the deterministic second pass.
 // a = wgrad(...) of the fp32 call: Y / ldy / M / N / K = R and the split-K scratch; a.X / a.W are not read.
@@ -645,6 +652,32 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
         if (!a.a_col && gemm_f32_small_eligible(a, small_ws_ok(a))) {
             VITA_TRY_RC(gemm_f32_t_check(a));
             return run_small(a, stream);
+        }
+        if (a.K >= tn_min_rows() && gemm_f32_tn_eligible(a)) {
+            // dW = dY^T X over many stacked rows: the tiles go to LDS as they lie in memory (vita_gemm_f32_tn.hip)
+            VITA_TRY_RC(gemm_f32_t_check(a));
+            SplitK sk;
+            const long tiles = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
+            if (a.splitk_ws != nullptr && (reinterpret_cast<uintptr_t>(a.splitk_ws) & 255u) == 0 && tiles < 256) {
+                long S = (256 + tiles - 1) / tiles;
+                const long by_r = a.K / 256;                       // at least 8 k-tiles of 32 rows per split
+                if (S > by_r) S = by_r;
+                const int64_t ldp = ((int64_t)a.N + 3) & ~int64_t(3);
+                const long by_ws = (long)(a.splitk_ws_bytes / ((size_t)a.M * ldp * sizeof(float)));
+                if (S > by_ws) S = by_ws;
+                if (S >= 2) {
+                    int rps = (int)((a.K + S - 1) / S);
+                    rps = (rps + 31) & ~31;
+                    sk.splits = (a.K + rps - 1) / rps;
+                    sk.k_per_split = rps;
+                    sk.partial = static_cast<float*>(a.splitk_ws);
+                    sk.ld_partial = ldp;
+                    if (sk.splits < 2) sk.splits = 1;
+                }
+            }
+            VITA_TRY_RC(gemm_f32_tn(a, stream, sk.splits > 1 ? &sk : nullptr));
+            if (sk.splits > 1) return launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream);
+            return VITA_OK;
         }
         const SplitK sk = (a.M > 0 && a.K > 0) ? plan_splitk(a) : SplitK{};
         VITA_TRY_RC(gemm_f32_t(a, stream, sk.splits > 1 ? &sk : nullptr));

@@ -62,6 +62,9 @@ int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipS
                   const EpiFold* fold = nullptr);
 // C (M, N) = A^T B for row-major bf16 A (R, M), B (R, N): the weight-gradient GEMM without transposed operand copies
 // (vita_gemm_bf16_tn.hip); gemm_bf16_wgrad_tn plans the split over R and runs the second pass (vita_gemm_f32.hip)
+// fp32 form (vita_gemm_f32_tn.hip): a = wgrad(...) with a_col = b_col = 1; eligible: 16-byte aligned rows, M, N, ldx, ldw % 4 == 0
+bool gemm_f32_tn_eligible(const vita_linear_args& a);
+int gemm_f32_tn(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 bool gemm_bf16_tn_eligible(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int R);
 int gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 int gemm_bf16_wgrad_tn(const uint16_t* dYb, int64_t ld_dy, const uint16_t* Xb, int64_t ldx, const vita_linear_args& a, hipStream_t stream);
