@@ -333,7 +333,7 @@ def main():
                   cfg.task.action_key: torch.randn(TB, 16, A, generator=gt).to(dev)}
         tts = torch.rand(64, TB, generator=gt).to(dev)
         tr.step_counter = 1000                           # past the lr warm-up, so the update is not a no-op
-        for i in range(3):
+        for i in range(3 if TB <= 1024 else 6):          # (the large-batch legs' first steps run on cold workspace pages)
             tr.train_step(tbatch, t=tts[i % 64])
         fence() if all_ranks else torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
@@ -388,13 +388,13 @@ def main():
             # BASELINE configs[2]: bf16-operand training, data parallel — at a per-GPU batch whose GEMMs take the bf16 kernels (the
             # default 128 rows per GPU stay fp32: none of their GEMMs reaches the 2^31-FLOP switch)
             try:
-                train_large_bf16 = train_leg(args.train_large_batch, "bf16", 5, True)
+                train_large_bf16 = train_leg(args.train_large_batch, "bf16", 10, True)
             except Exception as e:
                 train_large_bf16 = {"metric": "train samples/sec", "value": None, "error": f"{type(e).__name__}: {e}"[:400]}
         if world == 1 and args.train_large_batch > 0:
             # side figures at a batch that fills the chip: fp32, and BASELINE configs[2]'s bf16-operand training
-            train_large = train_leg(args.train_large_batch, "f32", 5, False)
-            train_large_bf16 = train_leg(args.train_large_batch, "bf16", 5, False)
+            train_large = train_leg(args.train_large_batch, "f32", 10, False)
+            train_large_bf16 = train_leg(args.train_large_batch, "bf16", 10, False)
             train_large_bf16["loss_rel_diff_vs_f32"] = float(f"{abs(train_large_bf16['loss'] - train_large['loss']) / abs(train_large['loss']):.3g}")
 
     # ---- per-kernel roofline: HIP events around the dominant GEMM classes, on the launch stream
