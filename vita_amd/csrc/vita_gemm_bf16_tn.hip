@@ -46,10 +46,29 @@ constexpr int TLDS = (TNS * TSTAGE > TBM * (TBN + 4) * 4) ? TNS * TSTAGE : TBM *
 
 __device__ __forceinline__ int tn_f(int r) { return ((r & 3) << 2) | ((r >> 2) & 3); }
 
-__device__ __forceinline__ s16x4 read_tr(const char* lds) {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)lds);
+// ds_read_b64_tr_b16 as inline asm, with the waits written by hand.  Through the builtin (__builtin_amdgcn_ds_read_tr16_b64_v4i16)
+// hipcc orders every such read behind ALL pending LDS-DMA of the wave -- an s_waitcnt vmcnt(0) in the middle of the k-loop, right
+// after the refills were issued -- which serialises operand delivery and compute (measured: 98 us for the 60-GFLOP weight gradient
+// against 59 us without the refills and 56 us with ONLY the refills).  The kernel's own counted vmcnt + barrier is what orders a
+// stage's reads behind its DMA.  `addr` is an LDS byte address.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+struct Frag { u32x2 lo, hi; };     // 8 bf16: one 32x32x16 operand
+template <int OFF>
+__device__ __forceinline__ void tr_issue(u32x2& d, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+// wait until at most N LDS reads of this wave are outstanding; the fragments are in/out operands so that nothing that uses them
+// (the MFMAs, a register copy the allocator might insert) is scheduled above the wait
+template <int N>
+__device__ __forceinline__ void tr_wait(Frag (&a)[2], Frag (&b)[2]) {
+    asm volatile("s_waitcnt lgkmcnt(%8)"
+                 : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(b[1].lo), "+v"(b[1].hi)
+                 : "n"(N)
+                 : "memory");
 }
 
+// LAB (timing only, results wrong): 1 = no operand refills inside the loop, 2 = refills only (no fragment reads, no MFMAs)
+template <int LAB>
 __global__ __launch_bounds__(TNT, 2) void gemm_bf16_tn_kernel(GemmParamsTN p) {
     extern __shared__ __attribute__((aligned(256))) float smem[];
     char* lds = reinterpret_cast<char*>(smem);
@@ -126,39 +145,65 @@ __global__ __launch_bounds__(TNT, 2) void gemm_bf16_tn_kernel(GemmParamsTN p) {
             b_off[i][h] = TBM * TBR * 2 + 256 * row + 16 * (cb ^ f) + 8 * (pp & 1);
         }
 
+    // fragments of one MFMA k-step (16 rows): 2 A + 2 B operands of 8 bf16, two transposed reads each (8 reads, issued in this order)
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+    auto read_step0 = [&](int stage, Frag (&af)[2], Frag (&bf)[2]) {
+        const unsigned sb = lds_base + stage * TSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            tr_issue<0>(af[i].lo, sb + a_off[i][0]);
+            tr_issue<0>(af[i].hi, sb + a_off[i][1]);
+            tr_issue<0>(bf[i].lo, sb + b_off[i][0]);
+            tr_issue<0>(bf[i].hi, sb + b_off[i][1]);
+        }
+    };
+    auto read_step1 = [&](int stage, Frag (&af)[2], Frag (&bf)[2]) {
+        const unsigned sb = lds_base + stage * TSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            tr_issue<4096>(af[i].lo, sb + a_off[i][0]);
+            tr_issue<4096>(af[i].hi, sb + a_off[i][1]);
+            tr_issue<4096>(bf[i].lo, sb + b_off[i][0]);
+            tr_issue<4096>(bf[i].hi, sb + b_off[i][1]);
+        }
+    };
+    auto mfma_step = [&](const Frag (&af)[2], const Frag (&bf)[2]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[i]), __builtin_bit_cast(bf16x8, bf[j]), acc[i][j], 0, 0, 0);
+    };
+
     wait_vmcnt<(TNS - 3) * DPT>();
     __syncthreads();
+    // software pipeline: the fragments of k-step s + 1 are requested before the MFMAs of k-step s, across k-tiles too -- after
+    // the barrier of iteration kt tile kt + 1 has landed for everyone (at most one tile is outstanding per wave), so its first
+    // fragments may be read while tile kt's second k-step multiplies.  LDS reads return in order: with the next step's 8 reads
+    // behind them, `lgkmcnt(8)` means this step's 8 have arrived.
+    Frag af0[2], bf0[2], af1[2], bf1[2];
+    read_step0(0, af0, bf0);
     int stage = 0;
     for (int kt = 0; kt < nk; ++kt) {
         int stage_new = stage + TNS - 1;
         stage_new = stage_new >= TNS ? stage_new - TNS : stage_new;
+        const int stage1 = stage + 1 == TNS ? 0 : stage + 1;
         if (kt > 0) {
-            wait_vmcnt<(TNS - 3) * DPT>();        // this wave's share of tile kt (and kt + 1) has landed ...
+            wait_vmcnt<(TNS - 3) * DPT>();        // this wave's share of tile kt + 1 has landed ...
             __builtin_amdgcn_s_barrier();         // ... everyone's has, and everyone is done reading tile kt - 1
             asm volatile("" ::: "memory");
         }
-        issue_tile(kt + TNS - 1, stage_new);      // past the last tile: zero chunks (r >= R)
-        const char* st = lds + stage * TSTAGE;
-        S16x8 af[2][2], bf[2][2];                 // [k-step][fragment]
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                af[ks][i].lo = read_tr(st + a_off[i][0] + ks * 4096);
-                af[ks][i].hi = read_tr(st + a_off[i][1] + ks * 4096);
-                bf[ks][i].lo = read_tr(st + b_off[i][0] + ks * 4096);
-                bf[ks][i].hi = read_tr(st + b_off[i][1] + ks * 4096);
-            }
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[ks][i]), __builtin_bit_cast(bf16x8, bf[ks][j]),
-                                                                        acc[i][j], 0, 0, 0);
-        stage = stage + 1 == TNS ? 0 : stage + 1;
+        if constexpr (LAB != 1) issue_tile(kt + TNS - 1, stage_new);      // past the last tile: zero chunks (r >= R)
+        if constexpr (LAB == 2) { stage = stage1; continue; }
+        read_step1(stage, af1, bf1);
+        tr_wait<8>(af0, bf0);
+        mfma_step(af0, bf0);
+        read_step0(stage1, af0, bf0);      // (past the last tile: a zero-filled or stale stage, never multiplied)
+        tr_wait<8>(af1, bf1);
+        mfma_step(af1, bf1);
+        stage = stage1;
     }
+    tr_wait<0>(af0, bf0);     // the last prefetch: nothing of this wave may be in flight when the stages are reused
     wait_vmcnt<0>();
     __syncthreads();      // every wave is done reading fragments, every DMA has landed: the stages become the output tile
     EpiParams e = p.epi;
@@ -192,7 +237,10 @@ int gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
         splits = sk->splits; p.sk_splits = splits; p.sk_r = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial;
     }
     const long blocks = (long)p.tiles_m * p.tiles_n * splits;
-    hipLaunchKernelGGL(gemm_bf16_tn_kernel, dim3((unsigned)blocks), dim3(TNT), TLDS, stream, p);
+    static const int lab = [] { const char* e = getenv("VITA_TN_LAB"); return e ? atoi(e) : 0; }();
+    if (lab == 1) hipLaunchKernelGGL(gemm_bf16_tn_kernel<1>, dim3((unsigned)blocks), dim3(TNT), TLDS, stream, p);
+    else if (lab == 2) hipLaunchKernelGGL(gemm_bf16_tn_kernel<2>, dim3((unsigned)blocks), dim3(TNT), TLDS, stream, p);
+    else hipLaunchKernelGGL(gemm_bf16_tn_kernel<0>, dim3((unsigned)blocks), dim3(TNT), TLDS, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
