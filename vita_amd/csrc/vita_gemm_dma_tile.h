@@ -334,6 +334,7 @@ __device__ __forceinline__ bool dma_tile(const GemmParamsDma& p, float* smem, in
         issue_tile(kt + NS - 1, stage_new);   // refills the stage tile kt-1 lived in (past the last tile: dummy reads of a
                                               // zero chunk; branching around them costs more than they do: fc2 loop +4 %)
 #endif
+#ifndef VITA_LAB_NOMFMA    // timing-only lab builds: operand delivery alone
 #pragma unroll
         for (int kc = 0; kc < NCH; ++kc) {
             if (kc + 1 < NCH) read_frags(stage, kt, kc + 1, af[(kc + 1) & 1], bf[(kc + 1) & 1], lm[(kc + 1) & 1], la[(kc + 1) & 1]);
@@ -358,6 +359,7 @@ __device__ __forceinline__ bool dma_tile(const GemmParamsDma& p, float* smem, in
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+#endif
         // the prefetched fragments must be in registers before the next barrier lets anyone
         // overwrite... (they belong to tile kt+1, which is not overwritten until kt+2) — only
         // the reads of tile kt must have retired, and they fed the MFMAs above.

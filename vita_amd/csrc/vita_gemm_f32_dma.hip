@@ -84,7 +84,7 @@ __global__ __launch_bounds__(DNT, OCC) void gemm_f32_dma_kernel(GemmParamsDma p)
 static thread_local char g_last_cfg[96] = "";
 const char* last_dma_config() { return g_last_cfg; }
 
-template <int BM, int BN, int BK, int NS>
+template <int BM, int BN, int BK, int NS, int OCC = 2, int KG = 1>
 static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
     GemmParamsDma p = p0;
     snprintf(g_last_cfg, sizeof(g_last_cfg), "gemm_f32_dma_kernel<%d,%d,%d,%d,bf16>", BM, BN, BK, NS);
@@ -93,9 +93,9 @@ static int launch_dma_bf16(const GemmParamsDma& p0, hipStream_t stream) {
     const size_t lds = ((size_t)NS * (BM + BN) * BK + (p.epi.ln_stats ? 2 * BM : 0)) * sizeof(float);
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * (p.sk_splits > 1 ? p.sk_splits : 1)));
     if (p.epi.act_grad_z != nullptr)
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true, 1, true>), grid, dim3(DNT), lds, stream, p);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC, true, KG, true>), grid, dim3(DNT), lds, stream, p);
     else
-        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, 2, true>), grid, dim3(DNT), lds, stream, p);
+        hipLaunchKernelGGL((gemm_f32_dma_kernel<BM, BN, BK, NS, false, OCC, true, KG>), grid, dim3(DNT), lds, stream, p);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
@@ -234,6 +234,10 @@ int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipS
     if (sk && sk->splits > 1) { p.sk_splits = sk->splits; p.sk_k = sk->k_per_split; p.epi.partial = sk->partial; p.epi.ld_partial = sk->ld_partial; }
     const long t128 = (long)((a.M + 127) / 128) * ((a.N + 127) / 128);
     if (t128 >= 512) return launch_dma_bf16<128, 128, 32, 4>(p, stream);
+    // (round 3 lab, same box, B = 4096 bf16 step with this tile / <64,128,64,3> / <64,128,64,3,KG=4>: 9.88 / 10.02 / 10.12 ms; alone the
+    // KG = 4 form is 10 % faster on warm operands (18.3 against 20.8 us at K = 2048), in the step it is not.  Timing-only builds without
+    // the refills / without the MFMAs take 12.5 / 13.0 us of the 19.2: delivery and compute add up instead of overlapping -- a wave
+    // that issues its 3 DMA pieces per k-tile has only 4 MFMAs = 128 cycles to put beside them)
     return launch_dma_bf16<64, 128, 32, 4>(p, stream);
 }
 
