@@ -817,7 +817,9 @@ def colsum(x: Tensor, out: Optional[Tensor] = None, accumulate: bool = False) ->
     x = _rows(x, "colsum: x")
     M, N = x.shape
     if out is None:
-        out = torch.zeros(N, dtype=torch.float32, device=x.device)
+        if accumulate:
+            raise L.VitaHipError("colsum: accumulate=True needs `out`")
+        out = torch.empty(N, dtype=torch.float32, device=x.device)     # (written, not accumulated: no fill launch in front)
     part = torch.empty(lib.vita_colsum_partials_count(N), dtype=torch.float32, device=x.device)
     L.check(lib.vita_colsum_f32(x.data_ptr(), _ld(x), M, N, part.data_ptr(), out.data_ptr(), int(accumulate), _stream(x)),
             "vita_colsum_f32")
