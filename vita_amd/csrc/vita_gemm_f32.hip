@@ -546,6 +546,7 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
     if (!a.a_col) {
         for (int i = 0; i < st.nsh; ++i)
             if (st.sh[i].src == a.X && st.sh[i].ld == Kp && st.sh[i].rows >= a.M && st.sh[i].cols == a.K) { xshadow = st.sh[i].bf; break; }
+        VITA_REQUIRE(xshadow != nullptr || !st.shadow_is_only(a.X), "vita_linear (bf16 step): the A operand exists only as a bf16 copy of another shape");
         if (xshadow != nullptr) st.shadow_drop(a.X);       // consumed
     }
     if (xshadow != nullptr) xa = const_cast<uint16_t*>(xshadow);
@@ -565,7 +566,7 @@ static int gemm_f32_via_bf16(const vita_linear_args& a, hipStream_t stream, bool
     if (emit && emit_only) { b.Y = nullptr; b.ldy = 0; }     // the caller reads only the bf16 copy
     VITA_TRY_RC(gemm_bf16_dma(b, emit ? emit_dst : nullptr, emit ? emit_ld : 0, stream, sk.splits > 1 ? &sk : nullptr));
     if (sk.splits > 1) VITA_TRY_RC(launch_splitk_reduce(epi_of(a), sk.partial, sk.ld_partial, sk.splits, stream));
-    if (emit) st.shadow_add(a.Y, emit_dst, emit_ld, a.M, a.N);
+    if (emit) st.shadow_add(a.Y, emit_dst, emit_ld, a.M, a.N, emit_only);
     *taken = true;
     return VITA_OK;
 }
@@ -632,6 +633,8 @@ int gemm_f32(const vita_linear_args& a, hipStream_t stream) {
         bool taken = false;
         VITA_TRY_RC(gemm_f32_via_bf16(a, stream, &taken));
         if (taken) return VITA_OK;
+        // (a producer that was told to skip its fp32 output relies on this call taking the bf16 route as well)
+        VITA_REQUIRE(!bf16_stage().shadow_is_only(a.X), "vita_linear (bf16 step): the A operand exists only as its bf16 copy, but this call cannot take the bf16 route");
     }
     if (!a.a_col && a.b_col && wt_cache().n > 0 && a.M >= kWtMinRows) {
         // dX = dY . W with W^T registered for this step (WtScope): an ordinary row-operand GEMM on the LDS-DMA kernels

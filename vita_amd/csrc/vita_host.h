@@ -143,17 +143,23 @@ struct Bf16WEntry { const float* w; const uint16_t* rows; const uint16_t* t; int
 // LayerNorm kernel's bf16 output) instead of by a pack launch in front of the GEMM that consumes them.  emit_*: a request to the
 // next bf16-routed GEMM whose output is emit_y to write such a copy.  A shadow is dropped when it is consumed, when its fp32
 // source is overwritten by a routed GEMM, and at the end of the scope.
-struct Bf16Shadow { const float* src; const uint16_t* bf; int64_t ld; int rows, cols; };
+struct Bf16Shadow { const float* src; const uint16_t* bf; int64_t ld; int rows, cols; bool only = false; };   // only: the fp32 matrix was NOT written (emit_only)
 struct Bf16Stage {
     void* ptr = nullptr; size_t bytes = 0; int mode = 0; Bf16WEntry wc[80]; int nwc = 0;
     Bf16Shadow sh[4]; int nsh = 0;
     const float* emit_y = nullptr; uint16_t* emit_dst = nullptr; int64_t emit_ld = 0;
     bool emit_only = false;     // with emit_y: when the bf16 copy IS written, skip the fp32 output (nobody reads it)
     uint16_t* arena = nullptr; size_t arena_halves = 0;      // shadow slots of the running step (vita_loss_step.hip)
-    void shadow_add(const float* src, const uint16_t* bf, int64_t ld, int rows, int cols) {
+    void shadow_add(const float* src, const uint16_t* bf, int64_t ld, int rows, int cols, bool only = false) {
         for (int i = 0; i < nsh; ++i)
-            if (sh[i].src == src) { sh[i] = Bf16Shadow{src, bf, ld, rows, cols}; return; }
-        if (nsh < 4) sh[nsh++] = Bf16Shadow{src, bf, ld, rows, cols};
+            if (sh[i].src == src) { sh[i] = Bf16Shadow{src, bf, ld, rows, cols, only}; return; }
+        if (nsh < 4) sh[nsh++] = Bf16Shadow{src, bf, ld, rows, cols, only};
+    }
+    // true when `src` exists ONLY as its bf16 copy: a GEMM that would read the fp32 matrix must not run
+    bool shadow_is_only(const float* src) const {
+        for (int i = 0; i < nsh; ++i)
+            if (sh[i].src == src && sh[i].only) return true;
+        return false;
     }
     bool has_shadow(const float* src, const uint16_t* bf) const {
         for (int i = 0; i < nsh; ++i)
