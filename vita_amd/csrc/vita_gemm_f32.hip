@@ -302,6 +302,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk, const EpiFold* fold = nullptr);
 int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
+int gemm_f32_t_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream);
 int gemm_f32_t_check(const vita_linear_args& a);
 int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws);
@@ -624,6 +625,22 @@ int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t st
     hipLaunchKernelGGL(splitk_reduce_fold_kernel, dim3((unsigned)(n / 256)), dim3(256), 0, stream, e, sk.partial, sk.ld_partial, sk.splits);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
+}
+
+// The two weight gradients of a layer (fc1, fc2) at few stacked rows: each alone has too few tiles for the chip and would split K
+// and pay a second pass; together, unsplit, they fill it once.  Falls back to two ordinary calls when the pair does not fit that
+// picture (bf16-operand step, many rows, tiles that do not fill the chip together, epilogue options).
+int gemm_f32_wgrad_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream) {
+    auto plain = [](const vita_linear_args& a) {
+        return a.a_col && a.b_col && a.X && a.W && a.Y && a.M > 0 && a.N > 0 && a.bias == nullptr && a.act_grad_z == nullptr && a.resid == nullptr &&
+               !a.use_gate_scalar && a.act == VITA_ACT_NONE && a.pro == VITA_PRO_NONE && a.gate == nullptr && a.preact == nullptr;
+    };
+    auto tiles = [](const vita_linear_args& a) { return (long)((a.M + 63) / 64) * ((a.N + 127) / 128); };
+    const long t = plain(a0) && plain(a1) ? tiles(a0) + tiles(a1) : 0;
+    if (bf16_stage().mode == 0 && t >= 192 && t <= 512 && a0.K == a1.K && a0.K >= 64 && a0.K < tn_min_rows())
+        return gemm_f32_t_pair(a0, a1, stream);
+    VITA_TRY_RC(gemm_f32(a0, stream));
+    return gemm_f32(a1, stream);
 }
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {

@@ -45,7 +45,7 @@ struct OpTile {
 };
 
 template <int BM, int BN, int BK, bool ACOL, bool BCOL, bool VEC>
-__global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
+__device__ __forceinline__ void gemm_f32_t_body(const GemmParamsT& p, const int block) {
     using TA = OpTile<BM, BK, ACOL>;
     using TB = OpTile<BN, BK, BCOL>;
     constexpr int TM = BM / 2, TN = BN / 4;
@@ -60,8 +60,8 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int nwg = p.tiles_m * p.tiles_n;
-    const int split = p.sk_splits > 1 ? (int)blockIdx.x / nwg : 0;
-    int bid = blockIdx.x - split * nwg;
+    const int split = p.sk_splits > 1 ? block / nwg : 0;
+    int bid = block - split * nwg;
     {
         const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
@@ -196,6 +196,20 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
     epilogue_dispatch<BM, BN, MI, NI, TNT, true>(acc, smem, e, m0, n0, wm, wn, lane, tid);
 }
 
+template <int BM, int BN, int BK, bool ACOL, bool BCOL, bool VEC>
+__global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
+    gemm_f32_t_body<BM, BN, BK, ACOL, BCOL, VEC>(p, (int)blockIdx.x);
+}
+
+// Two independent problems in one launch (the two weight gradients of a layer at few stacked rows: each alone fills half the
+// chip and would split K and pay a second pass): workgroups [0, n0) take the first, the rest the second.
+struct GemmParamsT2 { GemmParamsT p[2]; int n0; };
+template <int BM, int BN, int BK, bool ACOL, bool BCOL, bool VEC>
+__global__ __launch_bounds__(TNT) void gemm_f32_t_pair_kernel(GemmParamsT2 q) {
+    const int which = (int)blockIdx.x >= q.n0 ? 1 : 0;
+    gemm_f32_t_body<BM, BN, BK, ACOL, BCOL, VEC>(q.p[which], (int)blockIdx.x - (which ? q.n0 : 0));
+}
+
 template <bool ACOL, bool BCOL>
 static int launch_t(GemmParamsT p, bool vec, hipStream_t stream) {
     constexpr int BM = 64, BN = 128, BK = 32;
@@ -208,6 +222,8 @@ static int launch_t(GemmParamsT p, bool vec, hipStream_t stream) {
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }
+
+static GemmParamsT make_params_t(const vita_linear_args& a, const SplitK* sk, bool* vec_out);
 
 int gemm_f32_t_check(const vita_linear_args& a) {
     const char* who = "vita_linear_f32 (transposed operands)";
@@ -235,6 +251,35 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) 
         VITA_CHECK_HIP(hipMemset2DAsync(a.Y, (size_t)a.ldy * 4, 0, (size_t)a.N * 4, (size_t)a.M, stream));
         return VITA_OK;
     }
+    bool vec = false;
+    const GemmParamsT p = make_params_t(a, sk, &vec);
+    if (a.a_col && a.b_col) return launch_t<true, true>(p, vec, stream);
+    if (a.a_col) return launch_t<true, false>(p, vec, stream);
+    return launch_t<false, true>(p, vec, stream);
+}
+
+// dW_0 = dY_0^T X_0 and dW_1 = dY_1^T X_1 in ONE launch, no split-K (each problem's tiles reduce their whole K)
+int gemm_f32_t_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream) {
+    const char* who = "vita_linear_f32 (paired weight gradients)";
+    VITA_REQUIRE(a0.a_col && a0.b_col && a1.a_col && a1.b_col && a0.K > 0 && a1.K > 0, "%s: both calls must be weight gradients", who);
+    { const int rc = gemm_f32_t_check(a0); if (rc != VITA_OK) return rc; }
+    { const int rc = gemm_f32_t_check(a1); if (rc != VITA_OK) return rc; }
+    bool v0 = false, v1 = false;
+    GemmParamsT2 q{};
+    q.p[0] = make_params_t(a0, nullptr, &v0);
+    q.p[1] = make_params_t(a1, nullptr, &v1);
+    constexpr int BM = 64, BN = 128, BK = 32;
+    for (int i = 0; i < 2; ++i) { q.p[i].tiles_m = (q.p[i].M + BM - 1) / BM; q.p[i].tiles_n = (q.p[i].N + BN - 1) / BN; }
+    q.n0 = q.p[0].tiles_m * q.p[0].tiles_n;
+    const size_t lds = (size_t)3 * (OpTile<BM, BK, true>::BUF + OpTile<BN, BK, true>::BUF) * sizeof(float);
+    const dim3 grid((unsigned)(q.n0 + q.p[1].tiles_m * q.p[1].tiles_n)), block(TNT);
+    if (v0 && v1) hipLaunchKernelGGL((gemm_f32_t_pair_kernel<BM, BN, BK, true, true, true>), grid, block, lds, stream, q);
+    else hipLaunchKernelGGL((gemm_f32_t_pair_kernel<BM, BN, BK, true, true, false>), grid, block, lds, stream, q);
+    VITA_CHECK_HIP(hipGetLastError());
+    return VITA_OK;
+}
+
+static GemmParamsT make_params_t(const vita_linear_args& a, const SplitK* sk, bool* vec_out) {
     GemmParamsT p{};
     p.X = a.X; p.ldx = a.ldx; p.W = a.W; p.ldw = a.ldw; p.bias = a.bias; p.Y = a.Y; p.ldy = a.ldy;
     p.M = a.M; p.N = a.N; p.K = a.K;
@@ -251,10 +296,8 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) 
     auto al = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15u) == 0; };
     const bool vx = al(a.X) && a.ldx % 4 == 0 && (a.a_col ? a.M % 4 == 0 : a.K % 4 == 0);
     const bool vw = al(a.W) && a.ldw % 4 == 0 && (a.b_col ? a.N % 4 == 0 : a.K % 4 == 0);
-    const bool vec = vx && vw;
-    if (a.a_col && a.b_col) return launch_t<true, true>(p, vec, stream);
-    if (a.a_col) return launch_t<true, false>(p, vec, stream);
-    return launch_t<false, true>(p, vec, stream);
+    *vec_out = vx && vw;
+    return p;
 }
 
 }  // namespace vita

@@ -566,8 +566,8 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
             if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
             continue;
         }
-        VITA_TRY(gemm_f32(wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H), c.st));
-        VITA_TRY(gemm_f32(wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
+        VITA_TRY(gemm_f32_wgrad_pair(wgrad(c.Y2(l, 0), H, c.G(l, 0), FF, mut(g.fc2_w[l]), FF, R, FF, H),
+                                     wgrad(c.U(l, 0), FF, c.HN(l, 0), H, mut(g.fc1_w[l]), H, R, H, FF), c.st));
         if (layer_ready && layer_ready[l]) VITA_CHECK_HIP(hipEventRecord((hipEvent_t)layer_ready[l], c.st));
     }
     return VITA_OK;
