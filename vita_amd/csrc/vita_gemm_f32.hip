@@ -302,7 +302,7 @@ static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 int gemm_f32_dma(const vita_linear_args& a, hipStream_t stream, const SplitK* sk, const EpiFold* fold = nullptr);
 int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
-int gemm_f32_t_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream);
+int gemm_f32_t_batch(const vita_linear_args* a, int n, hipStream_t stream);
 int gemm_f32_t_check(const vita_linear_args& a);
 int gemm_f32_small(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 bool gemm_f32_small_eligible(const vita_linear_args& a, bool have_splitk_ws);
@@ -627,20 +627,36 @@ int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t st
     return VITA_OK;
 }
 
-// The two weight gradients of a layer (fc1, fc2) at few stacked rows: each alone has too few tiles for the chip and would split K
-// and pay a second pass; together, unsplit, they fill it once.  Falls back to two ordinary calls when the pair does not fit that
-// picture (bf16-operand step, many rows, tiles that do not fill the chip together, epilogue options).
-int gemm_f32_wgrad_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream) {
-    auto plain = [](const vita_linear_args& a) {
-        return a.a_col && a.b_col && a.X && a.W && a.Y && a.M > 0 && a.N > 0 && a.bias == nullptr && a.act_grad_z == nullptr && a.resid == nullptr &&
-               !a.use_gate_scalar && a.act == VITA_ACT_NONE && a.pro == VITA_PRO_NONE && a.gate == nullptr && a.preact == nullptr;
+// Weight gradients that are ready together (fc1 + fc2 of a flow layer; a whole decoder) at few stacked rows: each alone has too few
+// tiles for the chip and would split K and pay a second pass; together, unsplit, they fill it.  Calls that do not fit that picture
+// (bf16-operand step, many rows, epilogue options) and groups whose tiles would not fill half the chip run one by one.
+int gemm_f32_wgrad_batch(const vita_linear_args* a, int n, hipStream_t stream) {
+    auto plain = [](const vita_linear_args& x) {
+        return x.a_col && x.b_col && x.X && x.W && x.Y && x.M > 0 && x.N > 0 && x.K >= 64 && x.K < tn_min_rows() && x.bias == nullptr &&
+               x.act_grad_z == nullptr && x.resid == nullptr && !x.use_gate_scalar && x.act == VITA_ACT_NONE && x.pro == VITA_PRO_NONE &&
+               x.gate == nullptr && x.preact == nullptr;
     };
-    auto tiles = [](const vita_linear_args& a) { return (long)((a.M + 63) / 64) * ((a.N + 127) / 128); };
-    const long t = plain(a0) && plain(a1) ? tiles(a0) + tiles(a1) : 0;
-    if (bf16_stage().mode == 0 && t >= 192 && t <= 512 && a0.K == a1.K && a0.K >= 64 && a0.K < tn_min_rows())
-        return gemm_f32_t_pair(a0, a1, stream);
-    VITA_TRY_RC(gemm_f32(a0, stream));
-    return gemm_f32(a1, stream);
+    auto tiles = [](const vita_linear_args& x) { return (long)((x.M + 63) / 64) * ((x.N + 127) / 128); };
+    int i = 0;
+    while (i < n) {
+        // greedy groups of up to 8 consecutive eligible calls, at most 1024 tiles
+        int j = i;
+        long t = 0;
+        if (bf16_stage().mode == 0)
+            while (j < n && j - i < 8 && plain(a[j]) && t + tiles(a[j]) <= 1024) t += tiles(a[j++]);
+        if (j - i >= 2 && t >= 128) {
+            VITA_TRY_RC(gemm_f32_t_batch(a + i, j - i, stream));
+            i = j;
+        } else {
+            VITA_TRY_RC(gemm_f32(a[i], stream));
+            ++i;
+        }
+    }
+    return VITA_OK;
+}
+int gemm_f32_wgrad_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream) {
+    const vita_linear_args a[2] = {a0, a1};
+    return gemm_f32_wgrad_batch(a, 2, stream);
 }
 
 int gemm_f32(const vita_linear_args& a, hipStream_t stream) {

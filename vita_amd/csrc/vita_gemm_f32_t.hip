@@ -201,13 +201,17 @@ __global__ __launch_bounds__(TNT) void gemm_f32_t_kernel(GemmParamsT p) {
     gemm_f32_t_body<BM, BN, BK, ACOL, BCOL, VEC>(p, (int)blockIdx.x);
 }
 
-// Two independent problems in one launch (the two weight gradients of a layer at few stacked rows: each alone fills half the
-// chip and would split K and pay a second pass): workgroups [0, n0) take the first, the rest the second.
-struct GemmParamsT2 { GemmParamsT p[2]; int n0; };
+// Several independent problems in one launch (the weight gradients of a layer, or of a whole decoder, at few stacked rows: each
+// alone has too few tiles for the chip and would split K and pay a second pass): workgroups [start[i], start[i+1]) take problem i.
+constexpr int kBatchT = 8;
+struct GemmParamsTB { GemmParamsT p[kBatchT]; int start[kBatchT + 1]; int n; };
 template <int BM, int BN, int BK, bool ACOL, bool BCOL, bool VEC>
-__global__ __launch_bounds__(TNT) void gemm_f32_t_pair_kernel(GemmParamsT2 q) {
-    const int which = (int)blockIdx.x >= q.n0 ? 1 : 0;
-    gemm_f32_t_body<BM, BN, BK, ACOL, BCOL, VEC>(q.p[which], (int)blockIdx.x - (which ? q.n0 : 0));
+__global__ __launch_bounds__(TNT) void gemm_f32_t_batch_kernel(GemmParamsTB q) {
+    int which = 0;
+#pragma unroll
+    for (int i = 1; i < kBatchT; ++i)
+        if (i < q.n && (int)blockIdx.x >= q.start[i]) which = i;
+    gemm_f32_t_body<BM, BN, BK, ACOL, BCOL, VEC>(q.p[which], (int)blockIdx.x - q.start[which]);
 }
 
 template <bool ACOL, bool BCOL>
@@ -258,23 +262,27 @@ int gemm_f32_t(const vita_linear_args& a, hipStream_t stream, const SplitK* sk) 
     return launch_t<false, true>(p, vec, stream);
 }
 
-// dW_0 = dY_0^T X_0 and dW_1 = dY_1^T X_1 in ONE launch, no split-K (each problem's tiles reduce their whole K)
-int gemm_f32_t_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream) {
-    const char* who = "vita_linear_f32 (paired weight gradients)";
-    VITA_REQUIRE(a0.a_col && a0.b_col && a1.a_col && a1.b_col && a0.K > 0 && a1.K > 0, "%s: both calls must be weight gradients", who);
-    { const int rc = gemm_f32_t_check(a0); if (rc != VITA_OK) return rc; }
-    { const int rc = gemm_f32_t_check(a1); if (rc != VITA_OK) return rc; }
-    bool v0 = false, v1 = false;
-    GemmParamsT2 q{};
-    q.p[0] = make_params_t(a0, nullptr, &v0);
-    q.p[1] = make_params_t(a1, nullptr, &v1);
+// dW_i = dY_i^T X_i, i < n <= 8, in ONE launch, no split-K (each problem's tiles reduce their whole K)
+int gemm_f32_t_batch(const vita_linear_args* a, int n, hipStream_t stream) {
+    const char* who = "vita_linear_f32 (batched weight gradients)";
+    VITA_REQUIRE(a != nullptr && n >= 1 && n <= kBatchT, "%s: 1 to %d problems", who, kBatchT);
     constexpr int BM = 64, BN = 128, BK = 32;
-    for (int i = 0; i < 2; ++i) { q.p[i].tiles_m = (q.p[i].M + BM - 1) / BM; q.p[i].tiles_n = (q.p[i].N + BN - 1) / BN; }
-    q.n0 = q.p[0].tiles_m * q.p[0].tiles_n;
+    GemmParamsTB q{};
+    bool vec = true;
+    for (int i = 0; i < n; ++i) {
+        VITA_REQUIRE(a[i].a_col && a[i].b_col && a[i].K > 0, "%s: every call must be a weight gradient over at least one row", who);
+        { const int rc = gemm_f32_t_check(a[i]); if (rc != VITA_OK) return rc; }
+        bool v = false;
+        q.p[i] = make_params_t(a[i], nullptr, &v);
+        vec = vec && v;
+        q.p[i].tiles_m = (q.p[i].M + BM - 1) / BM; q.p[i].tiles_n = (q.p[i].N + BN - 1) / BN;
+        q.start[i + 1] = q.start[i] + q.p[i].tiles_m * q.p[i].tiles_n;
+    }
+    q.n = n;
     const size_t lds = (size_t)3 * (OpTile<BM, BK, true>::BUF + OpTile<BN, BK, true>::BUF) * sizeof(float);
-    const dim3 grid((unsigned)(q.n0 + q.p[1].tiles_m * q.p[1].tiles_n)), block(TNT);
-    if (v0 && v1) hipLaunchKernelGGL((gemm_f32_t_pair_kernel<BM, BN, BK, true, true, true>), grid, block, lds, stream, q);
-    else hipLaunchKernelGGL((gemm_f32_t_pair_kernel<BM, BN, BK, true, true, false>), grid, block, lds, stream, q);
+    const dim3 grid((unsigned)q.start[n]), block(TNT);
+    if (vec) hipLaunchKernelGGL((gemm_f32_t_batch_kernel<BM, BN, BK, true, true, true>), grid, block, lds, stream, q);
+    else hipLaunchKernelGGL((gemm_f32_t_batch_kernel<BM, BN, BK, true, true, false>), grid, block, lds, stream, q);
     VITA_CHECK_HIP(hipGetLastError());
     return VITA_OK;
 }

@@ -63,7 +63,9 @@ int gemm_bf16_dma(const vita_linear_args& a, uint16_t* ybf, int64_t ld_ybf, hipS
 // C (M, N) = A^T B for row-major bf16 A (R, M), B (R, N): the weight-gradient GEMM without transposed operand copies
 // (vita_gemm_bf16_tn.hip); gemm_bf16_wgrad_tn plans the split over R and runs the second pass (vita_gemm_f32.hip)
 // fp32 form (vita_gemm_f32_tn.hip): a = wgrad(...) with a_col = b_col = 1; eligible: 16-byte aligned rows, M, N, ldx, ldw % 4 == 0
-int gemm_f32_wgrad_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream);   // two wgrad() calls, one launch when that pays
+// wgrad() calls that are ready together: one unsplit launch per group of up to 8 when that fills the chip, else one by one
+int gemm_f32_wgrad_batch(const vita_linear_args* a, int n, hipStream_t stream);
+int gemm_f32_wgrad_pair(const vita_linear_args& a0, const vita_linear_args& a1, hipStream_t stream);
 bool gemm_f32_tn_eligible(const vita_linear_args& a);
 int gemm_f32_tn(const vita_linear_args& a, hipStream_t stream, const SplitK* sk);
 bool gemm_bf16_tn_eligible(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int M, int N, int R);

@@ -172,23 +172,39 @@ int stack_wgrads(const Stack& s, const Stack& g, const StackWs& w, const float* 
     auto dA = [&](int i) -> const float* { return (i == s.NL && !s.OUT) ? d_top : w.dA[i]; };
     auto ld_dA = [&](int i) -> int64_t { return (i == s.NL && !s.OUT) ? ld_top : s.TR; };
     ColsumBatch cb(cs_part, st);      // the bias gradients: one launch for the stack at few rows
+    const bool tn = w.tn() && bf16_stage().mode != 0;
+    if (!tn) {
+        // every weight gradient of the stack is ready here: at few rows they share launches (gemm_f32_wgrad_batch)
+        vita_linear_args jobs[2 * VITA_MAX_LAYERS + 2];
+        int nj = 0;
+        if (s.OUT) {
+            jobs[nj++] = wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT);
+            VITA_TRY(cb.add(d_top, ld_top, M, s.OUT, mut(g.out_b)));
+        }
+        for (int i = s.NL - 1; i >= 0; --i) {
+            const float* P = w.P + i * ff;
+            jobs[nj++] = wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR);
+            jobs[nj++] = wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF);
+            VITA_TRY(cb.add(dA(i + 1), ld_dA(i + 1), M, s.TR, mut(g.fc2_b[i])));
+            VITA_TRY(cb.add(P, s.FF, M, s.FF, mut(g.fc1_b[i])));
+        }
+        jobs[nj++] = wgrad(dA(0), ld_dA(0), x, ldx, mut(g.in_w), s.IN, M, s.IN, s.TR);
+        VITA_TRY(cb.add(dA(0), ld_dA(0), M, s.TR, mut(g.in_b)));
+        VITA_TRY(gemm_f32_wgrad_batch(jobs, nj, st));
+        return cb.flush();
+    }
+    // bf16-operand step at large batch: the layers' operands exist as row-major bf16 copies, as the forward / backward GEMMs left them
     if (s.OUT) {
         VITA_TRY(gemm_f32(wgrad(d_top, ld_top, trunk(s.NL), s.TR, mut(g.out_w), s.TR, M, s.TR, s.OUT), st));
         VITA_TRY(cb.add(d_top, ld_top, M, s.OUT, mut(g.out_b)));
     }
-    const bool tn = w.tn() && bf16_stage().mode != 0;
     const int tr8 = r8i(s.TR), ff8 = r8i(s.FF);
     for (int i = s.NL - 1; i >= 0; --i) {
         const float* P = w.P + i * ff;
-        if (tn) {   // the operands' bf16 copies as the forward / backward GEMMs left them
-            VITA_TRY(gemm_bf16_wgrad_tn(w.dAb[i + 1], tr8, w.Gb + (size_t)i * M * ff8, ff8,
-                                        wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
-            VITA_TRY(gemm_bf16_wgrad_tn(w.dPb + (size_t)i * M * ff8, ff8, w.Ab + (size_t)i * M * tr8, tr8,
-                                        wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
-        } else {
-            VITA_TRY(gemm_f32(wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
-            VITA_TRY(gemm_f32(wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
-        }
+        VITA_TRY(gemm_bf16_wgrad_tn(w.dAb[i + 1], tr8, w.Gb + (size_t)i * M * ff8, ff8,
+                                    wgrad(dA(i + 1), ld_dA(i + 1), w.G + i * ff, s.FF, mut(g.fc2_w[i]), s.FF, M, s.FF, s.TR), st));
+        VITA_TRY(gemm_bf16_wgrad_tn(w.dPb + (size_t)i * M * ff8, ff8, w.Ab + (size_t)i * M * tr8, tr8,
+                                    wgrad(P, s.FF, trunk(i), s.TR, mut(g.fc1_w[i]), s.TR, M, s.TR, s.FF), st));
         VITA_TRY(cb.add(dA(i + 1), ld_dA(i + 1), M, s.TR, mut(g.fc2_b[i])));
         VITA_TRY(cb.add(P, s.FF, M, s.FF, mut(g.fc1_b[i])));
     }
