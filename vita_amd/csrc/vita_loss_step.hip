@@ -408,12 +408,16 @@ int time_path_bwd(const FlowCtx& c, const vita_flownet_weights& g, int T, float*
         return VITA_OK;
     }
     ColsumBatch cb(cs_part, c.st);    // the bias gradients: one launch at the end (dmod, dte and dhid stay as they are until then)
+    {   // the modulators' weight gradients need only dmod and silu: ready now, one shared launch at few rows
+        vita_linear_args jobs[VITA_MAX_LAYERS];
+        for (int l = 0; l < L; ++l) jobs[l] = wgrad(c.f.dmod + (size_t)l * 3 * H, ldm, c.f.silu, H, mut(g.mod_w[l]), H, T, H, 3 * H);
+        VITA_TRY(gemm_f32_wgrad_batch(jobs, L, c.st));
+    }
     for (int l = 0; l < L; ++l) {
         const float* dm = c.f.dmod + (size_t)l * 3 * H;
         vita_linear_args a = dgrad(dm, ldm, w->mod_w[l], H, c.f.dsilu, H, T, H, 3 * H);
         if (l > 0) { a.resid = c.f.dsilu; a.ld_resid = H; }
         VITA_TRY(gemm_f32(a, c.st));
-        VITA_TRY(gemm_f32(wgrad(dm, ldm, c.f.silu, H, mut(g.mod_w[l]), H, T, H, 3 * H), c.st));
         VITA_TRY(cb.add(dm, ldm, T, 3 * H, mut(g.mod_b[l])));
     }
     VITA_TRY(vita_act_bwd_f32(c.f.tepre, c.f.dsilu, c.f.dte, (int64_t)T * H, VITA_ACT_SILU, c.st));
@@ -1914,9 +1918,9 @@ int vita_compute_loss_meanflow_f32(const vita_meanflow_policy_weights* w, const 
     };
     if (!per_layer) VITA_TRY(outer_wgrads());
     for (int l = 0; l < L; ++l) {
-        VITA_TRY(gemm_f32(wgrad(mc.DX(l + 1, 0), H, mc.S(l, 0), FF, mut(gf.fc2_w[l]), FF, R, FF, H), st));
+        VITA_TRY(gemm_f32_wgrad_pair(wgrad(mc.DX(l + 1, 0), H, mc.S(l, 0), FF, mut(gf.fc2_w[l]), FF, R, FF, H),
+                                     wgrad(mc.U1(l, 0), FF, mc.Xc(l, 0), H, mut(gf.fc1_w[l]), H, R, H, FF), st));
         VITA_TRY(vita_colsum_f32(mc.DX(l + 1, 0), H, R, H, s.cs_part, mut(gf.fc2_b[l]), 0, st));
-        VITA_TRY(gemm_f32(wgrad(mc.U1(l, 0), FF, mc.Xc(l, 0), H, mut(gf.fc1_w[l]), H, R, H, FF), st));
         VITA_TRY(vita_colsum_f32(mc.U1(l, 0), FF, R, FF, s.cs_part, mut(gf.fc1_b[l]), 0, st));
         if (per_layer) VITA_TRY(record(3 + l));
     }
