@@ -73,6 +73,12 @@ int gemm_bf16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb,
 int gemm_bf16_wgrad_tn(const uint16_t* dYb, int64_t ld_dy, const uint16_t* Xb, int64_t ldx, const vita_linear_args& a, hipStream_t stream);
 int launch_pack_bf16(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int64_t rows, int cols, hipStream_t s);
 int launch_pack_bf16_t(const float* src, int64_t ld_src, uint16_t* dst, int64_t ld_dst, int K, int M, hipStream_t s);
+// vita_layernorm_modulate_bwd_f32 with an optional fused gate backward on the new dx (the next kernel of the flow net's backward
+// chain): dz[row] = dx_new[row] * g[row], dg[row] = dx_new[row] * z[row]; z / dz are contiguous (M, H) and may be the same buffer
+struct LnGateTail { const float* z; const float* g; int64_t ld_g; float* dz; float* dg; int64_t ld_dg; };
+int launch_ln_mod_bwd(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul, int M, int H, float eps,
+                      int mode, float* dx, int64_t ld_dx, int dx_accumulate, float* dmul_rows, float* dadd_rows, int64_t ld_drows, hipStream_t s,
+                      const LnGateTail* tail);
 // vita_gate_bwd_f32 with an optional bf16 copy of dz (row stride ld_bf16) for the bf16-operand step
 int launch_gate_bwd(const float* dy, const float* z, const float* gate, int64_t ld_gate, float gate_scalar, float* dz, float* dgate_rows,
                     int64_t ld_dgate, int M, int N, hipStream_t s, uint16_t* dz_bf16, int64_t ld_bf16);

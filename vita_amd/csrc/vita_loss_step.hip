@@ -511,17 +511,25 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
     const bool sh = tn || (bs.mode != 0 && bs.arena != nullptr && (size_t)B * FF8 <= bs.arena_halves &&
                            (bs.mode == 2 || 2.0 * B * (double)FF * H >= kBf16MinFlops));
     VITA_TRY(gemm_f32(dgrad(c.DV(e), D, w->out_w, H, c.DHNF(e), H, B, H, D), c.st));
-    VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(L, e), H, c.DHNF(e), H, w->norm_w, 0, B, H, 1e-5f, VITA_PRO_LN_AFFINE, c.DH0(e), H, 0,
-                                             c.RN(e), nullptr, H, c.st));
+    // x_{l+1} = x_l + y2 * gamma: the gate backward of layer l reads the dx the LayerNorm backward above it has just made, so (fp32
+    // step) it runs as that kernel's tail -- one launch less per layer
+    auto gate_tail = [&](int l) {
+        return LnGateTail{c.Y2(l, e), mod + (size_t)l * 3 * H, ld_mod, c.Y2(l, e), dm_rows + (size_t)l * 3 * H, ldm};
+    };
+    const bool fuse_gate = !tn && L > 0;
+    {
+        const LnGateTail t = fuse_gate ? gate_tail(L - 1) : LnGateTail{};
+        VITA_TRY(launch_ln_mod_bwd(c.Hs(L, e), H, c.DHNF(e), H, w->norm_w, 0, B, H, 1e-5f, VITA_PRO_LN_AFFINE, c.DH0(e), H, 0, c.RN(e), nullptr, H,
+                                   c.st, fuse_gate ? &t : nullptr));
+    }
     for (int l = L - 1; l >= 0; --l) {
         const float* gamma = mod + (size_t)l * 3 * H;
         const float* scale = gamma + H;
         float* dmr = dm_rows + (size_t)l * 3 * H;
-        // x_{l+1} = x_l + y2 * gamma
         if (tn) {      // dY2's bf16 copy comes out of the kernel that makes dY2: the next GEMM's A operand, and the weight gradient's
             VITA_TRY(launch_gate_bwd(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st, c.Y2b(l, e), c.H8()));
             bs.shadow_add(c.Y2(l, e), c.Y2b(l, e), c.H8(), B, H);
-        } else {
+        } else if (!fuse_gate) {
             VITA_TRY(vita_gate_bwd_f32(c.DH0(e), c.Y2(l, e), gamma, ld_mod, 0.f, c.Y2(l, e), dmr, ldm, B, H, c.st));
         }
         vita_linear_args a = dgrad(c.Y2(l, e), H, w->fc2_w[l], FF, c.U(l, e), FF, B, FF, H);   // dU = (dY2 . W2) * gelu_tanh'(U)
@@ -532,8 +540,12 @@ int flow_chain_bwd(const FlowCtx& c, int e, int M, const float* mod, int64_t ld_
         if (tn && !bs.has_shadow(c.U(l, e), slot_du)) VITA_TRY(launch_pack_bf16(c.U(l, e), FF, slot_du, FF8, B, FF, c.st));
         VITA_TRY(gemm_f32(dgrad(c.U(l, e), FF, w->fc1_w[l], H, c.f.dhn, H, B, H, FF), c.st));
         bs.nsh = 0;
-        VITA_TRY(vita_layernorm_modulate_bwd_f32(c.Hs(l, e), H, c.f.dhn, H, scale, ld_mod, B, H, 1e-6f, VITA_PRO_LN_MOD, c.DH0(e), H, 1,
-                                                 dmr + H, dmr + 2 * H, ldm, c.st));
+        {
+            const bool tl = fuse_gate && l > 0;
+            const LnGateTail t = tl ? gate_tail(l - 1) : LnGateTail{};
+            VITA_TRY(launch_ln_mod_bwd(c.Hs(l, e), H, c.f.dhn, H, scale, ld_mod, B, H, 1e-6f, VITA_PRO_LN_MOD, c.DH0(e), H, 1, dmr + H, dmr + 2 * H, ldm,
+                                       c.st, tl ? &t : nullptr));
+        }
     }
     return VITA_OK;
 }

@@ -45,12 +45,14 @@ __global__ __launch_bounds__(TT) void gate_bwd_kernel(const float* __restrict__ 
 // NC = 16-byte chunks per lane (H <= 256*NC).  Everything the row needs (x, dy, the modulation row, the old dx when
 // accumulating) is requested before the first reduction: one memory round trip on the critical path instead of three.
 // VEC: every pointer 16-byte aligned and every stride a multiple of 4.
+// tail (LnGateTail, vita_host.h): the gate backward of the layer BELOW on the row's new dx -- dz = dx * g, dg = dx * z -- which in the
+// flow net's backward chain is the next kernel and reads exactly what this one has in registers (one launch less per layer).
 constexpr int LNB_MAXC = 8;
 template <int NC, bool VEC>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict__ x, int64_t ldx, const float* __restrict__ dy, int64_t ldd,
                                                          const float* __restrict__ mul, int64_t ld_mul, int M, int H, float eps, int mod,
                                                          float* __restrict__ dx, int64_t ld_dx, int dx_accumulate, float* __restrict__ dmul,
-                                                         float* __restrict__ dadd, int64_t ld_dma) {
+                                                         float* __restrict__ dadd, int64_t ld_dma, LnGateTail tail) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -79,7 +81,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
             }
         }
     };
-    f32x4 v[NC], g[NC], m[NC], old[NC];
+    f32x4 v[NC], g[NC], m[NC], old[NC], tz[NC], tg[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
         const int k = (c * 64 + lane) * 4;
@@ -87,6 +89,10 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
         g[c] = ld4(dr, k);
         m[c] = ld4(mr, k);
         if (acc) old[c] = ld4(ox, k);
+        if (tail.dz) {
+            tz[c] = ld4(tail.z + (int64_t)row * H, k);
+            tg[c] = ld4(tail.g + (int64_t)row * tail.ld_g, k);
+        }
     }
     float s = 0.f;
 #pragma unroll
@@ -143,6 +149,13 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(const float* __restrict
                 o[j] = acc ? old[c][j] + gx : gx;
             }
             st4(ox, k0, o);
+            if (tail.dz) {
+                f32x4 dgv, dzv;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { dgv[j] = o[j] * tz[c][j]; dzv[j] = o[j] * tg[c][j]; }
+                if (tail.dg) st4(tail.dg + (int64_t)row * tail.ld_dg, k0, dgv);
+                st4(tail.dz + (int64_t)row * H, k0, dzv);
+            }
         }
     }
 }
@@ -569,6 +582,19 @@ extern "C" {
 int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul, int32_t M,
                                     int32_t H, float eps, int32_t mode, float* dx, int64_t ld_dx, int32_t dx_accumulate, float* dmul_rows,
                                     float* dadd_rows, int64_t ld_drows, vita_stream_t s) {
+    return vita::launch_ln_mod_bwd(x, ldx, dy, ld_dy, mul, ld_mul, M, H, eps, mode, dx, ld_dx, dx_accumulate, dmul_rows, dadd_rows, ld_drows,
+                                   (hipStream_t)s, nullptr);
+}
+}  // extern "C"
+namespace vita {
+int launch_ln_mod_bwd(const float* x, int64_t ldx, const float* dy, int64_t ld_dy, const float* mul, int64_t ld_mul, int M, int H, float eps,
+                      int mode, float* dx, int64_t ld_dx, int dx_accumulate, float* dmul_rows, float* dadd_rows, int64_t ld_drows, hipStream_t s,
+                      const LnGateTail* tail_in) {
+    LnGateTail tail{};
+    if (tail_in) tail = *tail_in;
+    VITA_REQUIRE(tail.dz == nullptr || (dx != nullptr && tail.z != nullptr && tail.g != nullptr && (tail.ld_g == 0 || tail.ld_g >= H) &&
+                                        (tail.dg == nullptr || tail.ld_dg >= H)),
+                 "vita_layernorm_modulate_bwd_f32: the fused gate backward needs dx, z, g (row stride 0 or >= H) and ld_dg >= H");
     VITA_REQUIRE(x && dy && mul, "vita_layernorm_modulate_bwd_f32: null pointer");
     VITA_REQUIRE(M >= 0 && H > 0 && H <= 64 * 4 * LNB_MAXC, "vita_layernorm_modulate_bwd_f32: H=%d outside (0, %d]", H, 64 * 4 * LNB_MAXC);
     VITA_REQUIRE(ldx >= H && ld_dy >= H && (ld_mul == 0 || ld_mul >= H) && (dx == nullptr || ld_dx >= H), "vita_layernorm_modulate_bwd_f32: bad leading dimension");
@@ -576,16 +602,19 @@ int vita_layernorm_modulate_bwd_f32(const float* x, int64_t ldx, const float* dy
     VITA_REQUIRE((dmul_rows == nullptr && dadd_rows == nullptr) || ld_drows >= H, "vita_layernorm_modulate_bwd_f32: ld_drows must be >= H");
     if (M == 0) return VITA_OK;
     auto al = [](const void* q, int64_t ld) { return q == nullptr || ((reinterpret_cast<uintptr_t>(q) & 15u) == 0 && ld % 4 == 0); };
-    const bool vec = H % 4 == 0 && al(x, ldx) && al(dy, ld_dy) && al(mul, ld_mul) && al(dx, ld_dx) && al(dmul_rows, ld_drows) && al(dadd_rows, ld_drows);
+    const bool vec = H % 4 == 0 && al(x, ldx) && al(dy, ld_dy) && al(mul, ld_mul) && al(dx, ld_dx) && al(dmul_rows, ld_drows) && al(dadd_rows, ld_drows) &&
+                     al(tail.z, H) && al(tail.dz, H) && al(tail.g, tail.ld_g) && al(tail.dg, tail.ld_dg);
 #define VITA_LNB(NC, V)                                                                                                              \
     hipLaunchKernelGGL((ln_mod_bwd_kernel<NC, V>), dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)s, x, ldx, dy, ld_dy, mul, ld_mul, M, H, eps, \
-                       mode == VITA_PRO_LN_MOD ? 1 : 0, dx, ld_dx, dx_accumulate, dmul_rows, dadd_rows, ld_drows)
+                       mode == VITA_PRO_LN_MOD ? 1 : 0, dx, ld_dx, dx_accumulate, dmul_rows, dadd_rows, ld_drows, tail)
     if (H <= 512) { if (vec) VITA_LNB(2, true); else VITA_LNB(2, false); }
     else if (H <= 1024) { if (vec) VITA_LNB(4, true); else VITA_LNB(4, false); }
     else { if (vec) VITA_LNB(8, true); else VITA_LNB(8, false); }
 #undef VITA_LNB
     LAUNCH_OK();
 }
+}  // namespace vita
+extern "C" {
 int64_t vita_colsum_partials_count(int32_t N) { return (int64_t)CS_R4 * (N > 0 ? N : 0); }
 int vita_colsum_f32(const float* x, int64_t ldx, int32_t M, int32_t N, float* partials, float* out, int32_t accumulate, vita_stream_t s) {
     VITA_REQUIRE(x && partials && out && M >= 0 && N > 0 && ldx >= N, "vita_colsum_f32: bad arguments");
