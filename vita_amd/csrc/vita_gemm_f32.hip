@@ -629,7 +629,7 @@ int gemm_f32_fold(const vita_linear_args& a, const EpiFold& fold, hipStream_t st
 
 // Weight gradients that are ready together (fc1 + fc2 of a flow layer; a whole decoder) at few stacked rows: each alone has too few
 // tiles for the chip and would split K and pay a second pass; together, unsplit, they fill it.  Calls that do not fit that picture
-// (bf16-operand step, many rows, epilogue options) and groups whose tiles would not fill half the chip run one by one.
+// (bf16-operand step, many rows, epilogue options) and groups of fewer than 64 tiles run one by one.
 int gemm_f32_wgrad_batch(const vita_linear_args* a, int n, hipStream_t stream) {
     auto plain = [](const vita_linear_args& x) {
         return x.a_col && x.b_col && x.X && x.W && x.Y && x.M > 0 && x.N > 0 && x.K >= 64 && x.K < tn_min_rows() && x.bias == nullptr &&
@@ -644,7 +644,7 @@ int gemm_f32_wgrad_batch(const vita_linear_args* a, int n, hipStream_t stream) {
         long t = 0;
         if (bf16_stage().mode == 0)
             while (j < n && j - i < 8 && plain(a[j]) && t + tiles(a[j]) <= 1024) t += tiles(a[j++]);
-        if (j - i >= 2 && t >= 128) {
+        if (j - i >= 2 && t >= 64) {
             VITA_TRY_RC(gemm_f32_t_batch(a + i, j - i, stream));
             i = j;
         } else {

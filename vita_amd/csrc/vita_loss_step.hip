@@ -421,11 +421,12 @@ int time_path_bwd(const FlowCtx& c, const vita_flownet_weights& g, int T, float*
         VITA_TRY(cb.add(dm, ldm, T, 3 * H, mut(g.mod_b[l])));
     }
     VITA_TRY(vita_act_bwd_f32(c.f.tepre, c.f.dsilu, c.f.dte, (int64_t)T * H, VITA_ACT_SILU, c.st));
-    VITA_TRY(gemm_f32(wgrad(c.f.dte, H, c.f.hid, 4 * TE, mut(g.te3_w), 4 * TE, T, 4 * TE, H), c.st));
     vita_linear_args a = dgrad(c.f.dte, H, w->te3_w, 4 * TE, c.f.dhid, 4 * TE, T, 4 * TE, H);
     a.act = VITA_ACT_MISH; a.act_grad_z = c.f.hidpre; a.ld_act_grad_z = 4 * TE;
     VITA_TRY(gemm_f32(a, c.st));
-    VITA_TRY(gemm_f32(wgrad(c.f.dhid, 4 * TE, c.f.sin, TE, mut(g.te1_w), TE, T, TE, 4 * TE), c.st));
+    // (dte and dhid stay as they are: the two embedding weight gradients share a launch at few rows)
+    VITA_TRY(gemm_f32_wgrad_pair(wgrad(c.f.dte, H, c.f.hid, 4 * TE, mut(g.te3_w), 4 * TE, T, 4 * TE, H),
+                                 wgrad(c.f.dhid, 4 * TE, c.f.sin, TE, mut(g.te1_w), TE, T, TE, 4 * TE), c.st));
     VITA_TRY(cb.add(c.f.dte, H, T, H, mut(g.te3_b)));
     VITA_TRY(cb.add(c.f.dhid, 4 * TE, T, 4 * TE, mut(g.te1_b)));
     return cb.flush();
@@ -584,8 +585,8 @@ int flow_weight_grads(const FlowCtx& c, const vita_flownet_weights& g, float* cs
     }
     VITA_TRY(cb.flush());
     if (parts & kWgOuter) {
-        VITA_TRY(gemm_f32(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D), c.st));
-        VITA_TRY(gemm_f32(wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
+        VITA_TRY(gemm_f32_wgrad_pair(wgrad(c.f.DV, D, c.HN(L, 0), H, mut(g.out_w), H, R, H, D),
+                                     wgrad(c.f.DH0, H, c.f.X, D, mut(g.in_w), D, R, D, H), c.st));
     }
     Bf16Stage& bs = bf16_stage();
     const int H8 = c.H8(), FF8 = c.FF8();
